@@ -1,0 +1,265 @@
+/* az_math.h -- the numerics specification of the search path.
+ *
+ * Every elementary function the search needs (exp, log, sin, cos, logistic,
+ * softmax pieces, the JAX-style threefry generator and its uniform / gumbel
+ * transforms) is defined here as a fixed sequence of IEEE-754 binary32
+ * operations: +, -, *, /, sqrt and fused multiply-add, all correctly rounded
+ * on x86-64 and on gfx950.  Compiled with -ffp-contract=off on both sides the
+ * same inputs therefore give the same bits on the host and on the GPU, which
+ * is what lets the discrete outputs of the search (argmax results, visit
+ * counts, node indices) be compared bit for bit between a CPU run and a GPU
+ * run.  The polynomial cores are the classic Cephes single-precision kernels
+ * (expf, logf, sinf, cosf: < 1 ulp typical error), which is far inside the
+ * 1e-5 relative tolerance allowed against a libm / XLA evaluation.
+ *
+ * The header is written in the common subset of C99 and HIP C++ so that a
+ * plain C checker (gcc) and the device code (hipcc) include the very same
+ * text.  It contains no search logic.
+ */
+#ifndef AZ_MATH_H_
+#define AZ_MATH_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AZ_HD __host__ __device__ static __forceinline__
+#else
+#define AZ_HD static inline
+#endif
+
+#define AZ_INF (__builtin_inff())
+#define AZ_NAN (__builtin_nanf(""))
+#define AZ_FLT_TINY 1.17549435e-38f /* smallest normal binary32 (finfo.tiny) */
+#define AZ_FLT_MAX 3.40282347e+38f  /* finfo.max; finfo.min is its negation  */
+
+AZ_HD uint32_t az_f2u(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+AZ_HD float az_u2f(uint32_t u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+AZ_HD float az_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+AZ_HD float az_sqrtf(float x) { return __builtin_sqrtf(x); }
+AZ_HD int az_isnan(float x) { return x != x; }
+/* jnp.maximum / jnp.minimum propagate NaN. */
+AZ_HD float az_maxf(float a, float b) {
+  if (a != a) return a;
+  if (b != b) return b;
+  return a > b ? a : b;
+}
+AZ_HD float az_minf(float a, float b) {
+  if (a != a) return a;
+  if (b != b) return b;
+  return a < b ? a : b;
+}
+
+/* 2^k for -126 <= k <= 127 built from the exponent field. */
+AZ_HD float az_pow2i(int k) { return az_u2f((uint32_t)(k + 127) << 23); }
+
+/* exp(x).  k = round(x*log2(e)) by the add-magic-constant trick, Cody-Waite
+ * reduction r = x - k*ln2 in two fused steps, degree-5 polynomial on r^2 plus
+ * the linear terms, and a two-step power-of-two scaling so that results in the
+ * subnormal range are rounded once. */
+AZ_HD float az_expf(float x) {
+  if (x != x) return x;
+  if (x > 88.72283935546875f) return AZ_INF;
+  if (x < -103.97208404541015625f) return 0.0f;
+  float kf = (x * 1.44269502162933349609375f + 12582912.0f) - 12582912.0f;
+  float r = az_fmaf(kf, -0.693359375f, x);
+  r = az_fmaf(kf, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = az_fmaf(p, r, 1.3981999507e-3f);
+  p = az_fmaf(p, r, 8.3334519073e-3f);
+  p = az_fmaf(p, r, 4.1665795894e-2f);
+  p = az_fmaf(p, r, 1.6666665459e-1f);
+  p = az_fmaf(p, r, 5.0000001201e-1f);
+  p = az_fmaf(p, r * r, r);
+  p = p + 1.0f;
+  int k = (int)kf;
+  int k1 = k >> 1;
+  int k2 = k - k1;
+  return (p * az_pow2i(k1)) * az_pow2i(k2);
+}
+
+/* log(x): frexp by bit manipulation (subnormals pre-scaled by 2^23), the
+ * Cephes degree-8 polynomial on m - 1 with m in [sqrt(1/2), sqrt(2)). */
+AZ_HD float az_logf(float x) {
+  if (x != x) return x;
+  if (x < 0.0f) return AZ_NAN;
+  if (x == 0.0f) return -AZ_INF;
+  if (x == AZ_INF) return x;
+  int e = 0;
+  uint32_t ux = az_f2u(x);
+  if (ux < 0x00800000u) {
+    x = x * 8388608.0f;
+    e = -23;
+    ux = az_f2u(x);
+  }
+  e += (int)(ux >> 23) - 126;
+  float m = az_u2f((ux & 0x007fffffu) | 0x3f000000u);
+  if (m < 0.707106769084930419921875f) {
+    e -= 1;
+    m = (m + m) - 1.0f;
+  } else {
+    m = m - 1.0f;
+  }
+  float z = m * m;
+  float y = 7.0376836292e-2f;
+  y = az_fmaf(y, m, -1.1514610310e-1f);
+  y = az_fmaf(y, m, 1.1676998740e-1f);
+  y = az_fmaf(y, m, -1.2420140846e-1f);
+  y = az_fmaf(y, m, 1.4249322787e-1f);
+  y = az_fmaf(y, m, -1.6668057665e-1f);
+  y = az_fmaf(y, m, 2.0000714765e-1f);
+  y = az_fmaf(y, m, -2.4999993993e-1f);
+  y = az_fmaf(y, m, 3.3333331174e-1f);
+  y = (y * m) * z;
+  float fe = (float)e;
+  y = az_fmaf(fe, -2.12194440e-4f, y);
+  y = az_fmaf(-0.5f, z, y);
+  float res = m + y;
+  res = az_fmaf(fe, 0.693359375f, res);
+  return res;
+}
+
+/* Shared octant reduction for sin / cos: returns the reduced argument in
+ * [-pi/4, pi/4] and the octant index j (even, 0..6).  |x| >= 2^30 has no
+ * significant fraction left in binary32 and is mapped to 0 * x. */
+AZ_HD float az_trig_reduce_(float ax, int* j_out) {
+  int j = (int)(ax * 1.27323949337005615234375f); /* 4/pi */
+  float y = (float)j;
+  if (j & 1) {
+    j += 1;
+    y += 1.0f;
+  }
+  *j_out = j & 7;
+  float r;
+  if (ax > 8192.0f) {
+    r = az_fmaf(y, -0.785398185253143310546875f, ax);
+  } else {
+    r = az_fmaf(y, -0.78515625f, ax);
+    r = az_fmaf(y, -2.4187564849853515625e-4f, r);
+    r = az_fmaf(y, -3.77489497744594108e-8f, r);
+  }
+  return r;
+}
+AZ_HD float az_sin_poly_(float r) {
+  float z = r * r;
+  float p = -1.9515295891e-4f;
+  p = az_fmaf(p, z, 8.3321608736e-3f);
+  p = az_fmaf(p, z, -1.6666654611e-1f);
+  return az_fmaf(p * z, r, r);
+}
+AZ_HD float az_cos_poly_(float r) {
+  float z = r * r;
+  float p = 2.443315711809948e-5f;
+  p = az_fmaf(p, z, -1.388731625493765e-3f);
+  p = az_fmaf(p, z, 4.166664568298827e-2f);
+  float y = (p * z) * z;
+  y = az_fmaf(-0.5f, z, y);
+  return y + 1.0f;
+}
+AZ_HD float az_sinf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  if (!(ax < 1073741824.0f)) return 0.0f * x;
+  int j;
+  float r = az_trig_reduce_(ax, &j);
+  int neg = x < 0.0f;
+  if (j > 3) {
+    neg = !neg;
+    j -= 4;
+  }
+  float y = (j == 2) ? az_cos_poly_(r) : az_sin_poly_(r);
+  return neg ? -y : y;
+}
+AZ_HD float az_cosf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  if (!(ax < 1073741824.0f)) return 0.0f * x + (ax == AZ_INF ? 0.0f : 1.0f);
+  int j;
+  float r = az_trig_reduce_(ax, &j);
+  int neg = 0;
+  if (j > 3) {
+    neg = 1;
+    j -= 4;
+  }
+  if (j > 1) neg = !neg;
+  float y = (j == 2) ? az_sin_poly_(r) : az_cos_poly_(r);
+  return neg ? -y : y;
+}
+
+/* logistic(x) = 1 / (1 + exp(-x));  swish(x) = x * logistic(x). */
+AZ_HD float az_logistic(float x) { return 1.0f / (1.0f + az_expf(-x)); }
+AZ_HD float az_swish(float x) { return x * az_logistic(x); }
+/* x ** e for x >= 0 as exp(e * log(x)); e == 0 gives exactly 1 (also for
+ * x == 0), matching the power function's convention. */
+AZ_HD float az_powf(float x, float e) {
+  if (e == 0.0f) return 1.0f;
+  if (e == 1.0f) return x;
+  return az_expf(e * az_logf(x));
+}
+
+/* ------------------------------------------------------------------ */
+/* Threefry-2x32, 20 rounds (Salmon et al. 2011), the block function of
+ * JAX's default PRNG.  key = (k0, k1), counter = (x0, x1). */
+AZ_HD uint32_t az_rotl32(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+
+AZ_HD void az_threefry2x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
+                           uint32_t* o0, uint32_t* o1) {
+  uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  x0 += ks0;
+  x1 += ks1;
+#define AZ_TF_ROUND(r) \
+  x0 += x1;            \
+  x1 = az_rotl32(x1, r); \
+  x1 ^= x0;
+  AZ_TF_ROUND(13) AZ_TF_ROUND(15) AZ_TF_ROUND(26) AZ_TF_ROUND(6)
+  x0 += ks1; x1 += ks2 + 1u;
+  AZ_TF_ROUND(17) AZ_TF_ROUND(29) AZ_TF_ROUND(16) AZ_TF_ROUND(24)
+  x0 += ks2; x1 += ks0 + 2u;
+  AZ_TF_ROUND(13) AZ_TF_ROUND(15) AZ_TF_ROUND(26) AZ_TF_ROUND(6)
+  x0 += ks0; x1 += ks1 + 3u;
+  AZ_TF_ROUND(17) AZ_TF_ROUND(29) AZ_TF_ROUND(16) AZ_TF_ROUND(24)
+  x0 += ks1; x1 += ks2 + 4u;
+  AZ_TF_ROUND(13) AZ_TF_ROUND(15) AZ_TF_ROUND(26) AZ_TF_ROUND(6)
+  x0 += ks2; x1 += ks0 + 5u;
+#undef AZ_TF_ROUND
+  *o0 = x0;
+  *o1 = x1;
+}
+
+/* Key derivation and bit generation in the "partitionable" counter layout
+ * (the default of JAX >= 0.5): element i of a split / of a 32-bit draw uses
+ * the 64-bit counter (hi = 0, lo = i); a split keeps both output words as the
+ * new key, a 32-bit draw xors them. */
+AZ_HD void az_key_split(uint32_t k0, uint32_t k1, uint32_t i, uint32_t* o0,
+                        uint32_t* o1) {
+  az_threefry2x32(k0, k1, 0u, i, o0, o1);
+}
+AZ_HD uint32_t az_random_bits32(uint32_t k0, uint32_t k1, uint32_t i) {
+  uint32_t a, b;
+  az_threefry2x32(k0, k1, 0u, i, &a, &b);
+  return a ^ b;
+}
+/* 32 random bits -> float in [0, 1): mantissa fill of 1.0, minus 1. */
+AZ_HD float az_bits_to_unit(uint32_t bits) {
+  return az_u2f((bits >> 9) | 0x3f800000u) - 1.0f;
+}
+/* uniform(minval, maxval) from bits: f*(max-min)+min clamped below by min. */
+AZ_HD float az_uniform_from_bits(uint32_t bits, float minval, float maxval) {
+  float f = az_bits_to_unit(bits);
+  float v = f * (maxval - minval) + minval;
+  return v > minval ? v : minval;
+}
+/* standard Gumbel from bits: -log(-log(u)), u ~ uniform(tiny, 1). */
+AZ_HD float az_gumbel_from_bits(uint32_t bits) {
+  float u = az_uniform_from_bits(bits, AZ_FLT_TINY, 1.0f);
+  return -az_logf(-az_logf(u));
+}
+
+#endif /* AZ_MATH_H_ */
