@@ -1,0 +1,45 @@
+"""Core types of the policy API (mirrors mctx_dist/_src/base.py).
+
+Arrays are torch tensors on the GPU.  `value` may be `[B]` (the scalar layout
+of mctx/_src/base.py) or `[B, num_atoms]` (mctx_dist/_src/base.py); the layout
+of the returned Tree follows the root's.
+"""
+import dataclasses
+from typing import Any, Callable, Generic, Tuple, TypeVar
+
+T = TypeVar("T")
+
+
+class _Replaceable:
+    def replace(self, **changes):
+        return dataclasses.replace(self, **changes)
+
+
+@dataclasses.dataclass(frozen=True)
+class RecurrentFnOutput(_Replaceable):
+    """mctx_dist/_src/base.py:34-46: reward [B], discount [B], prior_logits [B,A], value [B(,K)]."""
+    reward: Any
+    discount: Any
+    prior_logits: Any
+    value: Any
+
+
+@dataclasses.dataclass(frozen=True)
+class RootFnOutput(_Replaceable):
+    """mctx_dist/_src/base.py:57-66: prior_logits [B,A], value [B(,K)], embedding pytree [B,...]."""
+    prior_logits: Any
+    value: Any
+    embedding: Any
+
+
+@dataclasses.dataclass(frozen=True)
+class PolicyOutput(_Replaceable, Generic[T]):
+    """mctx_dist/_src/base.py:87-99: action [B] int32, action_weights [B,A], search_tree."""
+    action: Any
+    action_weights: Any
+    search_tree: Any
+
+
+Params = Any
+RecurrentState = Any
+RecurrentFn = Callable[[Params, Any, Any, RecurrentState], Tuple[RecurrentFnOutput, RecurrentState]]

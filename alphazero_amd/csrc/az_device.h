@@ -1,0 +1,467 @@
+// az_device.h -- per-lane device functions of the batched tree search.
+//
+// One batch lane = one independent tree.  The tree arrays live in HBM in the
+// reference's layout (mctx_dist/_src/tree.py:60-73); a Lane<> is the view of one
+// lane's slices.  All arithmetic is binary32 in the order the reference writes it
+// and uses the elementary functions of az_math.h, so the integer outputs (actions,
+// visit counts, node indices) equal those of a host evaluation bit for bit.
+//
+// AMAX / KMAX are compile-time bounds on the number of actions / value atoms so
+// that the per-action vectors stay in registers; the run-time A <= AMAX, K <= KMAX.
+#ifndef AZ_DEVICE_H_
+#define AZ_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/az_mcts.h"
+#include "az_math.h"
+
+#define AZ_ROOT 0
+#define AZ_UNVISITED (-1)
+
+#define AZ_DEV __device__ __forceinline__
+
+// Loops over actions / atoms: fully unrolled for compile-time bounds up to 8 (the
+// vectors then live in registers), plain run-time loops for the generic bound.
+// The enclosing function must have `A` (resp. `K`) in scope.
+constexpr int az_uf(int n) { return n <= 8 ? n : 1; }
+#define AZ_UNROLL_A _Pragma("unroll az_uf(AMAX)")
+#define AZ_TRIP_A (AMAX <= 8 ? AMAX : A)
+#define AZ_UNROLL_K _Pragma("unroll az_uf(KMAX)")
+#define AZ_TRIP_K (KMAX <= 8 ? KMAX : K)
+
+template <int AMAX, int KMAX>
+struct Lane {
+  int A, K;
+  int32_t *nv, *par, *afp, *cidx, *cvis;
+  float *raw, *nval, *clog, *crew, *cdisc, *cval;
+  float* es;
+  int32_t* et;
+
+  AZ_DEV Lane(const az_tree& t, int b, int N, int A_, int K_) : A(A_), K(K_) {
+    size_t bn = (size_t)b * N;
+    nv = t.node_visits + bn;
+    par = t.parents + bn;
+    afp = t.action_from_parent + bn;
+    cidx = t.children_index + bn * A;
+    cvis = t.children_visits + bn * A;
+    raw = t.raw_values + bn * K;
+    nval = t.node_values + bn * K;
+    clog = t.children_prior_logits + bn * A;
+    crew = t.children_rewards + bn * A;
+    cdisc = t.children_discounts + bn * A;
+    cval = t.children_values + bn * A * K;
+    es = t.emb_state ? t.emb_state + bn * 4 : nullptr;
+    et = t.emb_time ? t.emb_time + bn : nullptr;
+  }
+};
+
+// jnp.argmax: first maximal element, NaN counts as maximal.
+template <int AMAX>
+AZ_DEV int az_argmax(const float (&x)[AMAX], int A) {
+  int best = 0;
+  float bv = x[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a) {
+    if (a < A) {
+      float v = x[a];
+      if ((v > bv) || (v != v && bv == bv)) {
+        best = a;
+        bv = v;
+      }
+    }
+  }
+  return best;
+}
+
+// jax.nn.softmax: exp(x - max) / sum, left-to-right sum.
+template <int AMAX>
+AZ_DEV void az_softmax(const float (&x)[AMAX], int A, float (&out)[AMAX]) {
+  float m = x[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A) m = az_maxf(m, x[a]);
+  float s = 0.0f;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      out[a] = az_expf(x[a] - m);
+      s = s + out[a];
+    }
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) out[a] = out[a] / s;
+}
+
+// Row `node` of the per-action statistics, loaded once per selection step.
+template <int AMAX>
+struct NodeRow {
+  int32_t vis[AMAX];
+  float logits[AMAX];
+  float q[AMAX];  // mean over atoms of reward + discount * child value
+};
+
+// mctx_dist/_src/tree.py:142-147 + the mean over atoms every qtransform applies first.
+template <int AMAX, int KMAX>
+AZ_DEV void az_load_row(const Lane<AMAX, KMAX>& l, int node, NodeRow<AMAX>& r) {
+  const int A = l.A, K = l.K;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a) {
+    if (a < A) {
+      r.vis[a] = l.cvis[node * A + a];
+      r.logits[a] = l.clog[node * A + a];
+      float rw = l.crew[node * A + a], dc = l.cdisc[node * A + a];
+      const float* cv = l.cval + ((size_t)node * A + a) * K;
+      float s = 0.0f;
+      if (KMAX == 1) {
+        s = s + (rw + dc * cv[0]);
+      } else {
+        for (int k = 0; k < K; ++k) s = s + (rw + dc * cv[k]);
+      }
+      r.q[a] = s / (float)K;
+    }
+  }
+}
+
+template <int AMAX, int KMAX>
+AZ_DEV float az_mean_atoms(const float* x, int K) {
+  float s = 0.0f;
+  if (KMAX == 1) {
+    s = s + x[0];
+  } else {
+    for (int k = 0; k < K; ++k) s = s + x[k];
+  }
+  return s / (float)K;
+}
+
+// mctx_dist/_src/qtransforms.py:54-87
+template <int AMAX, int KMAX>
+AZ_DEV void az_qt_parent_siblings(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
+                                  const NodeRow<AMAX>& r, float (&out)[AMAX]) {
+  const int A = l.A;
+  float v = az_mean_atoms<AMAX, KMAX>(l.nval + (size_t)node * l.K, l.K);
+  float lo = r.vis[0] > 0 ? r.q[0] : v;
+  float hi = lo;
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float safe = r.vis[a] > 0 ? r.q[a] : v;
+      lo = az_minf(lo, safe);
+      hi = az_maxf(hi, safe);
+    }
+  lo = az_minf(v, lo);
+  hi = az_maxf(v, hi);
+  float den = az_maxf(hi - lo, d.q_epsilon);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float cm = r.vis[a] > 0 ? r.q[a] : lo;
+      out[a] = (cm - lo) / den;
+    }
+}
+
+// mctx_dist/_src/qtransforms.py:24-51
+template <int AMAX, int KMAX>
+AZ_DEV void az_qt_min_max(const Lane<AMAX, KMAX>& l, const az_search_desc& d,
+                          const NodeRow<AMAX>& r, float (&out)[AMAX]) {
+  const int A = l.A;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float s = r.vis[a] > 0 ? r.q[a] : d.min_value;
+      out[a] = (s - d.min_value) / (d.max_value - d.min_value);
+    }
+}
+
+// mctx_dist/_src/qtransforms.py:90-149, 152-198
+template <int AMAX, int KMAX>
+AZ_DEV void az_qt_completed_mix(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
+                                const NodeRow<AMAX>& r, float (&out)[AMAX]) {
+  const int A = l.A;
+  float raw = az_mean_atoms<AMAX, KMAX>(l.raw + (size_t)node * l.K, l.K);
+  float value;
+  if (d.use_mixed_value) {
+    float probs[AMAX];
+    az_softmax<AMAX>(r.logits, A, probs);
+    int32_t sum_visits = 0;
+    float sum_probs = 0.0f;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        sum_visits += r.vis[a];
+        probs[a] = az_maxf(AZ_FLT_TINY, probs[a]);
+        sum_probs = sum_probs + (r.vis[a] > 0 ? probs[a] : 0.0f);
+      }
+    float weighted_q = 0.0f;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        float term = r.vis[a] > 0 ? (probs[a] * r.q[a]) / sum_probs : 0.0f;
+        weighted_q = weighted_q + term;
+      }
+    value = (raw + (float)sum_visits * weighted_q) / (float)(sum_visits + 1);
+  } else {
+    value = raw;
+  }
+  float cq[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) cq[a] = r.vis[a] > 0 ? r.q[a] : value;
+  if (d.rescale_values) {
+    float mn = cq[0], mx = cq[0];
+AZ_UNROLL_A
+    for (int a = 1; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        mn = az_minf(mn, cq[a]);
+        mx = az_maxf(mx, cq[a]);
+      }
+    float den = az_maxf(mx - mn, d.q_epsilon);
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) cq[a] = (cq[a] - mn) / den;
+  }
+  int32_t maxvisit = r.vis[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A && r.vis[a] > maxvisit) maxvisit = r.vis[a];
+  float visit_scale = d.maxvisit_init + (float)maxvisit;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) out[a] = (visit_scale * d.value_scale) * cq[a];
+}
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_qtransform(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
+                          const NodeRow<AMAX>& r, float (&out)[AMAX]) {
+  if (d.qtransform == AZ_QT_PARENT_SIBLINGS)
+    az_qt_parent_siblings<AMAX, KMAX>(l, d, node, r, out);
+  else if (d.qtransform == AZ_QT_COMPLETED_MIX)
+    az_qt_completed_mix<AMAX, KMAX>(l, d, node, r, out);
+  else
+    az_qt_min_max<AMAX, KMAX>(l, d, r, out);
+}
+
+// mctx_dist/_src/seq_halving.py:23-33
+template <int AMAX>
+AZ_DEV void az_score_considered(int32_t considered_visit, const float* gumbel,
+                                const float (&logits)[AMAX], const float (&nq)[AMAX],
+                                const int32_t (&vis)[AMAX], int A, float (&out)[AMAX]) {
+  float mx = logits[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A) mx = az_maxf(mx, logits[a]);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float lg = logits[a] - mx;
+      float penalty = vis[a] == considered_visit ? 0.0f : -AZ_INF;
+      out[a] = az_maxf(-1e9f, (gumbel[a] + lg) + nq[a]) + penalty;
+    }
+}
+
+// Everything a selection step needs besides the tree.
+struct SearchCtx {
+  az_search_desc d;
+  az_search_inputs in;
+};
+
+// mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled).
+template <int AMAX, int KMAX>
+AZ_DEV int az_select_puct(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, int node, int depth,
+                          const float (&noise)[AMAX]) {
+  const az_search_desc& d = c.d;
+  const int A = l.A;
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, node, r);
+  int32_t node_visit = l.nv[node];
+  float pb_c = d.pb_c_init + az_logf((((float)node_visit + d.pb_c_base) + 1.0f) / d.pb_c_base);
+  float probs[AMAX], value_score[AMAX], to_argmax[AMAX];
+  if (d.variant == AZ_VARIANT_MUZERO) {
+    az_softmax<AMAX>(r.logits, A, probs);
+  } else {
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a) probs[a] = r.logits[a];
+  }
+  az_qtransform<AMAX, KMAX>(l, d, node, r, value_score);
+  float sq = az_sqrtf((float)node_visit);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float policy_score = ((sq * pb_c) * probs[a]) / (float)(r.vis[a] + 1);
+      float v = (value_score[a] + policy_score) + noise[a];
+      // action_selection.py:90: mask = root_invalid_actions * (depth == 0)
+      bool masked = depth == 0 && c.in.invalid_actions != nullptr &&
+                    c.in.invalid_actions[(size_t)b * A + a] != 0.0f;
+      to_argmax[a] = masked ? -AZ_INF : v;
+    }
+  return az_argmax<AMAX>(to_argmax, A);
+}
+
+// mctx_dist/_src/action_selection.py:148-200
+template <int AMAX, int KMAX>
+AZ_DEV int az_select_gumbel_root(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, int node) {
+  const az_search_desc& d = c.d;
+  const int A = l.A;
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, node, r);
+  float cq[AMAX], score[AMAX];
+  az_qtransform<AMAX, KMAX>(l, d, node, r, cq);
+  const float* inv = c.in.invalid_actions ? c.in.invalid_actions + (size_t)b * A : nullptr;
+  float nvalid = 0.0f;
+  int32_t sim_index = 0;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      nvalid = nvalid + (1.0f - (inv ? inv[a] : 0.0f));
+      sim_index += r.vis[a];
+    }
+  int32_t num_valid = (int32_t)nvalid;
+  int32_t num_considered = d.max_num_considered < num_valid ? d.max_num_considered : num_valid;
+  if (num_considered < 0) num_considered = 0;
+  if (sim_index > d.S - 1) sim_index = d.S - 1;
+  int32_t considered_visit = c.in.table[(size_t)num_considered * d.S + sim_index];
+  az_score_considered<AMAX>(considered_visit, c.in.root_gumbel + (size_t)b * A, r.logits, cq, r.vis,
+                            A, score);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A && inv && inv[a] != 0.0f) score[a] = -AZ_INF;
+  return az_argmax<AMAX>(score, A);
+}
+
+// mctx_dist/_src/action_selection.py:203-240, 256-277
+template <int AMAX, int KMAX>
+AZ_DEV int az_select_gumbel_interior(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int node) {
+  const int A = l.A;
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, node, r);
+  float cq[AMAX], x[AMAX], probs[AMAX], to_argmax[AMAX];
+  az_qtransform<AMAX, KMAX>(l, c.d, node, r, cq);
+  int32_t sum_visits = 0;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      x[a] = r.logits[a] + cq[a];
+      sum_visits += r.vis[a];
+    }
+  az_softmax<AMAX>(x, A, probs);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) to_argmax[a] = probs[a] - (float)r.vis[a] / (float)(1 + sum_visits);
+  return az_argmax<AMAX>(to_argmax, A);
+}
+
+// mctx_dist/_src/search.py:127-187 with the root/interior switch of
+// action_selection.py:28-45.  (k0,k1) = split(simulate_key, B)[b].
+template <int AMAX, int KMAX>
+AZ_DEV void az_simulate_lane(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, int sim,
+                             uint32_t k0, uint32_t k1, int& parent, int& action, int& next,
+                             int& depth_out) {
+  const az_search_desc& d = c.d;
+  const int A = l.A;
+  int node = AZ_ROOT, depth = 0, act = -1, nxt = AZ_ROOT;
+  for (;;) {
+    node = nxt;
+    if (d.variant != AZ_VARIANT_GUMBEL) {
+      float noise[AMAX];
+      if (d.noise_mode == AZ_NOISE_THREEFRY) {
+        uint32_t n0, n1, s0, s1;  // rng_key, action_selection_key = split(rng_key)
+        az_key_split(k0, k1, 0u, &n0, &n1);
+        az_key_split(k0, k1, 1u, &s0, &s1);
+        k0 = n0;
+        k1 = n1;
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a < A)
+            noise[a] = 1e-7f * az_uniform_from_bits(az_random_bits32(s0, s1, (uint32_t)a), 0.0f, 1.0f);
+      } else if (d.noise_mode == AZ_NOISE_INJECTED) {
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a < A) {
+            float u = depth < d.noise_depth
+                          ? c.in.noise[(((size_t)b * d.S + sim) * d.noise_depth + depth) * A + a]
+                          : 0.0f;
+            noise[a] = 1e-7f * u;
+          }
+      } else {
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
+      }
+      act = az_select_puct<AMAX, KMAX>(c, l, b, node, depth, noise);
+    } else if (depth == 0) {
+      act = az_select_gumbel_root<AMAX, KMAX>(c, l, b, node);
+    } else {
+      act = az_select_gumbel_interior<AMAX, KMAX>(c, l, node);
+    }
+    nxt = l.cidx[node * A + act];
+    depth += 1;
+    if (!(nxt != AZ_UNVISITED && depth < d.max_depth)) break;
+  }
+  parent = node;
+  action = act;
+  next = nxt;
+  depth_out = depth;
+}
+
+// mctx_dist/_src/search.py:231-244, 304-342: the tree writes of expand.
+template <int AMAX, int KMAX>
+AZ_DEV void az_expand_write(const Lane<AMAX, KMAX>& l, int parent, int action, int node,
+                            const float* logits, const float* value, float reward, float discount) {
+  const int A = l.A, K = l.K;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) l.clog[node * A + a] = logits[a];
+  if (KMAX == 1) {
+    l.raw[node] = value[0];
+    l.nval[node] = value[0];
+  } else {
+    for (int k = 0; k < K; ++k) {
+      l.raw[(size_t)node * K + k] = value[k];
+      l.nval[(size_t)node * K + k] = value[k];
+    }
+  }
+  l.nv[node] = l.nv[node] + 1;
+  l.cidx[parent * A + action] = node;
+  l.crew[parent * A + action] = reward;
+  l.cdisc[parent * A + action] = discount;
+  l.par[node] = parent;
+  l.afp[node] = action;
+}
+
+// mctx_dist/_src/search.py:247-292
+template <int AMAX, int KMAX>
+AZ_DEV void az_backward_lane(const Lane<AMAX, KMAX>& l, int leaf) {
+  const int A = l.A, K = l.K;
+  float lv[KMAX];
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k) lv[k] = k < K ? l.nval[(size_t)leaf * K + k] : 0.0f;
+  int index = leaf;
+  while (index != AZ_ROOT) {
+    int parent = l.par[index];
+    int32_t count = l.nv[parent];
+    int action = l.afp[index];
+    float reward = l.crew[parent * A + action];
+    float disc = l.cdisc[parent * A + action];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) {
+        lv[k] = reward + disc * lv[k];
+        float pv = (l.nval[(size_t)parent * K + k] * (float)count + lv[k]) / ((float)count + 1.0f);
+        l.nval[(size_t)parent * K + k] = pv;
+        l.cval[((size_t)parent * A + action) * K + k] = l.nval[(size_t)index * K + k];
+      }
+    l.cvis[parent * A + action] = l.cvis[parent * A + action] + 1;
+    l.nv[parent] = count + 1;
+    index = parent;
+  }
+}
+
+// per-simulation keys: rng, simulate_key, expand_key = split(rng, 3)  (search.py:90)
+AZ_DEV void az_next_sim_key(uint32_t& r0, uint32_t& r1, uint32_t& s0, uint32_t& s1) {
+  uint32_t n0, n1;
+  az_key_split(r0, r1, 1u, &s0, &s1);
+  az_key_split(r0, r1, 0u, &n0, &n1);
+  r0 = n0;
+  r1 = n1;
+}
+
+#endif  // AZ_DEVICE_H_

@@ -1,0 +1,318 @@
+// az_fused.hip -- the in-tree model: weight packing, network forward, recurrent step and the fused persistent search.
+// Part of libaz_mcts.so (gfx950 only); built with -ffp-contract=off, which is part of
+// the numerics contract (every fused multiply-add is an explicit az_fmaf, az_math.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "az_host.h"
+#include "az_envs.h"
+#include "az_mlp.h"
+
+// ---------------------------------------------------------------------------
+// model: weight packing, forward, recurrent step
+static int az_check_mlp(const az_mlp_params* p, const char* name) {
+  if (!p) return az_fail(AZ_ERR_INVALID, "null %s network", name);
+  if (p->n_layers < 1 || p->n_layers > AZ_MAX_LAYERS)
+    return az_fail(AZ_ERR_UNSUPPORTED, "%s network has %d layers (1..%d supported)", name,
+                   p->n_layers, AZ_MAX_LAYERS);
+  for (int i = 0; i <= p->n_layers; ++i)
+    if (p->sizes[i] < 1 || p->sizes[i] > AZ_MAX_WIDTH)
+      return az_fail(AZ_ERR_UNSUPPORTED, "%s layer width %d outside [1,%d]", name, p->sizes[i],
+                     AZ_MAX_WIDTH);
+  return AZ_OK;
+}
+
+extern "C" int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params* value) {
+  if (az_check_mlp(policy, "policy") || az_check_mlp(value, "value")) return -1;
+  MlpLayout lp, lv;
+  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &lp);
+  return az_mlp_layout(value->n_layers, value->sizes, off, &lv);
+}
+
+__global__ void k_pack_layer(const float* __restrict__ w, const float* __restrict__ bsrc, int kin,
+                             int nout, int kp, int np, float* __restrict__ wp,
+                             float* __restrict__ bp) {
+  const int64_t total = (int64_t)kp * np;
+  const int nkb = kp >> 4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const int64_t blk = e >> 8;  // t * nkb + kb
+    const int kb = (int)(blk % nkb), t = (int)(blk / nkb);
+    const int k = 16 * kb + 4 * q + (lane >> 4), n = 16 * t + (lane & 15);
+    wp[e] = (k < kin && n < nout) ? w[(size_t)k * nout + n] : 0.0f;
+  }
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < np; n += gridDim.x * blockDim.x)
+    bp[n] = n < nout ? bsrc[n] : 0.0f;
+}
+
+extern "C" int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
+                             void* stream) {
+  if (int rc = az_check_mlp(policy, "policy")) return rc;
+  if (int rc = az_check_mlp(value, "value")) return rc;
+  if (!packed) return az_fail(AZ_ERR_INVALID, "null packed buffer");
+  MlpLayout L[2];
+  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &L[0]);
+  az_mlp_layout(value->n_layers, value->sizes, off, &L[1]);
+  const az_mlp_params* P[2] = {policy, value};
+  for (int net = 0; net < 2; ++net)
+    for (int i = 0; i < L[net].n_layers; ++i) {
+      if (!P[net]->w[i] || !P[net]->b[i]) return az_fail(AZ_ERR_INVALID, "null layer weights");
+      const int64_t total = (int64_t)L[net].kp[i] * L[net].np[i];
+      const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+      k_pack_layer<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
+          P[net]->w[i], P[net]->b[i], L[net].kin[i], L[net].nout[i], L[net].kp[i], L[net].np[i],
+          packed + L[net].w_off[i], packed + L[net].b_off[i]);
+      AZ_LAUNCH_CHECK();
+    }
+  return AZ_OK;
+}
+
+static int az_model_dev(const az_model* m, ModelDev* md) {
+  if (!m) return az_fail(AZ_ERR_INVALID, "null model");
+  if (m->env_id < AZ_ENV_CARTPOLE || m->env_id > AZ_ENV_ACROBOT)
+    return az_fail(AZ_ERR_UNSUPPORTED, "unknown env_id %d", m->env_id);
+  if (!m->packed || !m->norm_mean || !m->norm_std)
+    return az_fail(AZ_ERR_INVALID, "model has null buffers");
+  az_mlp_params pp{}, vp{};
+  pp.n_layers = m->policy_layers;
+  vp.n_layers = m->value_layers;
+  if (pp.n_layers < 1 || pp.n_layers > AZ_MAX_LAYERS || vp.n_layers < 1 || vp.n_layers > AZ_MAX_LAYERS)
+    return az_fail(AZ_ERR_UNSUPPORTED, "layer count outside 1..%d", AZ_MAX_LAYERS);
+  memcpy(pp.sizes, m->policy_sizes, sizeof pp.sizes);
+  memcpy(vp.sizes, m->value_sizes, sizeof vp.sizes);
+  if (int rc = az_check_mlp(&pp, "policy")) return rc;
+  if (int rc = az_check_mlp(&vp, "value")) return rc;
+  const int od = az_env_obs_dim(m->env_id), na = az_env_num_actions(m->env_id);
+  if (m->obs_dim != od || pp.sizes[0] != od || vp.sizes[0] != od)
+    return az_fail(AZ_ERR_INVALID, "network input width must equal the observation size %d", od);
+  if (m->num_actions != na || pp.sizes[pp.n_layers] != na)
+    return az_fail(AZ_ERR_INVALID, "policy output width must equal the %d actions", na);
+  if (m->num_atoms != vp.sizes[vp.n_layers] || m->num_atoms > AZ_MAX_ATOMS)
+    return az_fail(AZ_ERR_INVALID, "value output width must equal num_atoms (<= %d)", AZ_MAX_ATOMS);
+  md->env_id = m->env_id;
+  md->gamma = m->gamma;
+  md->obs_dim = od;
+  md->A = na;
+  md->K = m->num_atoms;
+  int64_t off = az_mlp_layout(pp.n_layers, pp.sizes, 0, &md->pol);
+  az_mlp_layout(vp.n_layers, vp.sizes, off, &md->val);
+  int mk = 16;
+  for (int i = 0; i < md->pol.n_layers; ++i) mk = md->pol.np[i] > mk ? md->pol.np[i] : mk;
+  for (int i = 0; i < md->val.n_layers; ++i) mk = md->val.np[i] > mk ? md->val.np[i] : mk;
+  md->max_kp = mk;
+  md->packed = m->packed;
+  md->mean = m->norm_mean;
+  md->std = m->norm_std;
+  if ((size_t)az_mlp_lds_floats(mk) * 4 > 160 * 1024)
+    return az_fail(AZ_ERR_UNSUPPORTED, "layer width %d needs more than 160 KiB of LDS", mk);
+  return AZ_OK;
+}
+
+#define AZ_MLP_WAVES 8
+
+struct MlpLds {
+  float *in0, *bufa, *bufb, *logits, *value;
+  int stride;
+  AZ_DEV MlpLds(float* base, int max_kp) {
+    stride = az_act_stride(max_kp);
+    in0 = base;
+    bufa = in0 + 16 * stride;
+    bufb = bufa + 16 * stride;
+    logits = bufb + 16 * stride;
+    value = logits + 16 * AZ_MAX_ACTIONS;
+  }
+};
+
+// running_statistics.py:183-199 on one observation row, written in the permuted
+// activation layout of the first dense layer (Kp = 16).
+AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
+  for (int i = 0; i < md.obs_dim; ++i)
+    s.in0[row * s.stride + az_act_index(i, 16)] = (obs[i] - md.mean[i]) / md.std[i];
+}
+
+// both networks on the 16 rows staged in s.in0 -> s.logits / s.value
+AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane) {
+  az_mlp_tile16<AZ_MLP_WAVES>(md.pol, md.packed, s.in0, s.bufa, s.bufb, s.logits, AZ_MAX_ACTIONS,
+                              s.stride, wave, lane);
+  az_mlp_tile16<AZ_MLP_WAVES>(md.val, md.packed, s.in0, s.bufa, s.bufb, s.value, AZ_MAX_ATOMS,
+                              s.stride, wave, lane);
+}
+
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
+                                                               const float* __restrict__ obs,
+                                                               float* __restrict__ logits,
+                                                               float* __restrict__ value) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  MlpLds s(lds, md.max_kp);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  __syncthreads();
+  const int b = blockIdx.x * 16 + tid;
+  if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
+  __syncthreads();
+  az_forward_tile(md, s, wave, lane);
+  if (tid < 16 && b < B) {
+    for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
+    for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
+  }
+}
+
+static int az_set_lds(const void* fn, size_t bytes) {
+  if (bytes > 48 * 1024)
+    AZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return AZ_OK;
+}
+
+extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float* logits,
+                          float* value, void* stream) {
+  ModelDev md;
+  if (int rc = az_model_dev(m, &md)) return rc;
+  if (B < 1 || !obs || !logits || !value) return az_fail(AZ_ERR_INVALID, "bad forward arguments");
+  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  if (int rc = az_set_lds((const void*)k_forward, lds)) return rc;
+  k_forward<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
+      md, B, obs, logits, value);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// alphazero.py:317-339 on one lane: environment step, reward and discount.
+AZ_DEV void az_model_env_step(const ModelDev& md, EnvState& st, int action, EnvOut& o, float& reward,
+                              float& discount) {
+  az_env_step_rt(md.env_id, st, action, o);
+  reward = o.reward;
+  discount = md.gamma * (o.truncated != 0.0f ? 1.0f : 1.0f - o.terminated);
+}
+
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
+    ModelDev md, int B, float* __restrict__ state, int32_t* __restrict__ time,
+    const int32_t* __restrict__ action, float* __restrict__ reward, float* __restrict__ discount,
+    float* __restrict__ logits, float* __restrict__ value) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  MlpLds s(lds, md.max_kp);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  __syncthreads();
+  const int b = blockIdx.x * 16 + tid;
+  if (tid < 16 && b < B) {
+    EnvState st;
+    EnvOut o;
+    for (int i = 0; i < 4; ++i) st.s[i] = state[(size_t)b * 4 + i];
+    st.time = time[b];
+    float r, dsc;
+    az_model_env_step(md, st, action[b], o, r, dsc);
+    for (int i = 0; i < 4; ++i) state[(size_t)b * 4 + i] = st.s[i];
+    time[b] = st.time;
+    reward[b] = r;
+    discount[b] = dsc;
+    az_store_obs(md, s, tid, o.obs);
+  }
+  __syncthreads();
+  az_forward_tile(md, s, wave, lane);
+  if (tid < 16 && b < B) {
+    for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
+    for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
+  }
+}
+
+extern "C" int az_recurrent_step(const az_model* m, int32_t B, float* state, int32_t* time,
+                                 const int32_t* action, float* reward, float* discount,
+                                 float* logits, float* value, void* stream) {
+  ModelDev md;
+  if (int rc = az_model_dev(m, &md)) return rc;
+  if (B < 1 || !state || !time || !action || !reward || !discount || !logits || !value)
+    return az_fail(AZ_ERR_INVALID, "bad recurrent_step arguments");
+  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  if (int rc = az_set_lds((const void*)k_recurrent_step, lds)) return rc;
+  k_recurrent_step<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
+      md, B, state, time, action, reward, discount, logits, value);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the fused persistent search: 16 lanes per workgroup; per simulation the first 16
+// threads select + step the environment, all waves run the two MLPs on the matrix
+// cores, then the 16 threads expand and back up.
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c, az_tree t,
+                                                                    ModelDev md,
+                                                                    unsigned long long* sum_depth) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const az_search_desc& d = c.d;
+  MlpLds s(lds, md.max_kp);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x * 16 + tid;
+  const bool active = tid < 16 && b < d.B;
+  Lane<AMAX, KMAX> l(t, active ? b : 0, d.S + 1, d.A, d.K);
+  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  __syncthreads();
+  const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
+  uint32_t r0 = d.key[0], r1 = d.key[1];
+  long long depth_sum = 0;
+  for (int sim = 0; sim < d.S; ++sim) {
+    int parent = 0, action = 0, node = 0;
+    float reward = 0.0f, discount = 0.0f;
+    EnvState st;
+    if (active) {
+      uint32_t k0 = 0, k1 = 0;
+      if (need_keys) {
+        uint32_t s0, s1;
+        az_next_sim_key(r0, r1, s0, s1);
+        az_key_split(s0, s1, (uint32_t)b, &k0, &k1);
+      }
+      int nxt, depth;
+      az_simulate_lane<AMAX, KMAX>(c, l, b, sim, k0, k1, parent, action, nxt, depth);
+      node = nxt == AZ_UNVISITED ? sim + 1 : nxt;
+      depth_sum += depth;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
+      st.time = l.et[parent];
+      EnvOut o;
+      az_model_env_step(md, st, action, o, reward, discount);
+      az_store_obs(md, s, tid, o.obs);
+    }
+    __syncthreads();
+    az_forward_tile(md, s, wave, lane);
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l.es[(size_t)node * 4 + i] = st.s[i];
+      l.et[node] = st.time;
+      az_expand_write<AMAX, KMAX>(l, parent, action, node, s.logits + tid * AZ_MAX_ACTIONS,
+                                  s.value + tid * AZ_MAX_ATOMS, reward, discount);
+      az_backward_lane<AMAX, KMAX>(l, node);
+    }
+  }
+  if (tid < 64) az_add_depth(sum_depth, depth_sum);
+}
+
+extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
+                               const az_search_inputs* in, const az_model* m, int64_t* sum_depth,
+                               void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (int rc = az_check_inputs(d, in)) return rc;
+  ModelDev md;
+  if (int rc = az_model_dev(m, &md)) return rc;
+  if (!t->emb_state || !t->emb_time)
+    return az_fail(AZ_ERR_INVALID, "fused search needs the tree's emb_state / emb_time arrays");
+  if (d->A != md.A || d->K != md.K)
+    return az_fail(AZ_ERR_INVALID, "search A=%d K=%d do not match the model's A=%d K=%d", d->A,
+                   d->K, md.A, md.K);
+  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  SearchCtx c{*d, *in};
+  return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+    if (int rc = az_set_lds((const void*)k_search_fused<AMAX, KMAX>, lds)) return rc;
+    k_search_fused<AMAX, KMAX>
+        <<<dim3((d->B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
+            c, *t, md, reinterpret_cast<unsigned long long*>(sum_depth));
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  });
+}
+

@@ -1,0 +1,52 @@
+// az_host.h -- host-side helpers shared by the translation units of libaz_mcts.so:
+// the thread-local error channel, argument checks and the (AMAX, KMAX) dispatch.
+#ifndef AZ_HOST_H_
+#define AZ_HOST_H_
+
+#include <hip/hip_runtime.h>
+
+#include "az_device.h"
+
+int az_fail(int code, const char* fmt, ...);
+int az_check_desc(const az_search_desc* d, const az_tree* t);
+int az_check_inputs(const az_search_desc* d, const az_search_inputs* in);
+
+#define AZ_HIP(call)                                                                 \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      return az_fail(AZ_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+  } while (0)
+
+#define AZ_LAUNCH_CHECK()                                                            \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess)                                                            \
+      return az_fail(AZ_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// Compile-time bounds (AMAX, KMAX) for a run-time (A, K).  Bounds up to 8 keep the
+// per-action / per-atom vectors in registers (fully unrolled loops); the largest
+// bound is a generic path with run-time loops.
+template <typename F>
+static int az_dispatch_ak(int A, int K, F&& f) {
+#define AZ_K_CASES(AM)                                  \
+  if (K == 1) return f.template operator()<AM, 1>();    \
+  if (K <= 8) return f.template operator()<AM, 8>();    \
+  return f.template operator()<AM, AZ_MAX_ATOMS>();
+  if (A <= 2) { AZ_K_CASES(2) }
+  if (A <= 3) { AZ_K_CASES(3) }
+  if (A <= 4) { AZ_K_CASES(4) }
+  if (A <= 8) { AZ_K_CASES(8) }
+  AZ_K_CASES(AZ_MAX_ACTIONS)
+#undef AZ_K_CASES
+}
+
+// wave-level sum of a per-thread counter, one atomic per wave
+AZ_DEV void az_add_depth(unsigned long long* dst, long long v) {
+  if (!dst) return;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dst, (unsigned long long)v);
+}
+
+#endif  // AZ_HOST_H_

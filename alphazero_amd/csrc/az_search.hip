@@ -1,0 +1,263 @@
+// az_search.hip -- tree initialisation, the persistent tree search with injected evaluations, the per-simulation kernels and the Gumbel epilogue.
+// Part of libaz_mcts.so (gfx950 only); built with -ffp-contract=off, which is part of
+// the numerics contract (every fused multiply-add is an explicit az_fmaf, az_math.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "az_host.h"
+
+// ---------------------------------------------------------------------------
+// tree init: one thread per (lane, node)
+__global__ void k_tree_init(az_search_desc d, az_tree t, const float* __restrict__ root_logits,
+                            const float* __restrict__ root_value,
+                            const float* __restrict__ root_state,
+                            const int32_t* __restrict__ root_time) {
+  const int N = d.S + 1, A = d.A, K = d.K;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.B * N) return;
+  const int b = (int)(i / N), n = (int)(i % N);
+  const bool root = n == 0;
+  t.node_visits[i] = root ? 1 : 0;
+  t.parents[i] = -1;
+  t.action_from_parent[i] = -1;
+  for (int k = 0; k < K; ++k) {
+    float v = root ? root_value[(size_t)b * K + k] : 0.0f;
+    t.raw_values[i * K + k] = v;
+    t.node_values[i * K + k] = v;
+  }
+  for (int a = 0; a < A; ++a) {
+    t.children_index[i * A + a] = AZ_UNVISITED;
+    t.children_prior_logits[i * A + a] = root ? root_logits[(size_t)b * A + a] : 0.0f;
+    t.children_visits[i * A + a] = 0;
+    t.children_rewards[i * A + a] = 0.0f;
+    t.children_discounts[i * A + a] = 0.0f;
+    for (int k = 0; k < K; ++k) t.children_values[(i * A + a) * K + k] = 0.0f;
+  }
+  if (t.emb_state)
+    for (int j = 0; j < 4; ++j)
+      t.emb_state[i * 4 + j] = (root && root_state) ? root_state[(size_t)b * 4 + j] : 0.0f;
+  if (t.emb_time) t.emb_time[i] = (root && root_time) ? root_time[b] : 0;
+}
+
+extern "C" int az_tree_init(const az_search_desc* d, const az_tree* t, const float* root_logits,
+                            const float* root_value, const float* root_state,
+                            const int32_t* root_time, void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (!root_logits || !root_value) return az_fail(AZ_ERR_INVALID, "null root arrays");
+  const size_t total = (size_t)d->B * (d->S + 1);
+  k_tree_init<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      *d, *t, root_logits, root_value, root_state, root_time);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// persistent tree search with injected evaluations: one thread per lane
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(64) void k_search_injected(SearchCtx c, az_tree t, az_injected inj,
+                                                        unsigned long long* sum_depth) {
+  const az_search_desc& d = c.d;
+  const int A = d.A, K = d.K;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  long long depth_sum = 0;
+  if (b < d.B) {
+    Lane<AMAX, KMAX> l(t, b, d.S + 1, d.A, d.K);
+    const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
+    uint32_t r0 = d.key[0], r1 = d.key[1];
+    for (int sim = 0; sim < d.S; ++sim) {
+      uint32_t k0 = 0, k1 = 0;
+      if (need_keys) {
+        uint32_t s0, s1;
+        az_next_sim_key(r0, r1, s0, s1);
+        az_key_split(s0, s1, (uint32_t)b, &k0, &k1);
+      }
+      int parent, action, nxt, depth;
+      az_simulate_lane<AMAX, KMAX>(c, l, b, sim, k0, k1, parent, action, nxt, depth);
+      const int node = nxt == AZ_UNVISITED ? sim + 1 : nxt;
+      depth_sum += depth;
+      const size_t e = (size_t)b * d.S + sim;
+      float logits[AMAX], value[KMAX];
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < d.A) logits[a] = inj.prior_logits[e * d.A + a];
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < d.K) value[k] = inj.value[e * d.K + k];
+      az_expand_write<AMAX, KMAX>(l, parent, action, node, logits, value, inj.reward[e],
+                                  inj.discount[e]);
+      az_backward_lane<AMAX, KMAX>(l, node);
+    }
+  }
+  az_add_depth(sum_depth, depth_sum);
+}
+
+extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
+                                  const az_search_inputs* in, const az_injected* inj,
+                                  int64_t* sum_depth, void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (int rc = az_check_inputs(d, in)) return rc;
+  if (!inj || !inj->prior_logits || !inj->value || !inj->reward || !inj->discount)
+    return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
+  SearchCtx c{*d, *in};
+  return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+    k_search_injected<AMAX, KMAX><<<dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+        c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// per-simulation kernels for an arbitrary caller-side recurrent_fn
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(64) void k_simulate(SearchCtx c, az_tree t, int sim, uint32_t s0,
+                                                 uint32_t s1, int32_t* __restrict__ parent_out,
+                                                 int32_t* __restrict__ action_out,
+                                                 int32_t* __restrict__ next_out,
+                                                 unsigned long long* sum_depth) {
+  const az_search_desc& d = c.d;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  long long depth_sum = 0;
+  if (b < d.B) {
+    Lane<AMAX, KMAX> l(t, b, d.S + 1, d.A, d.K);
+    uint32_t k0 = 0, k1 = 0;
+    if (d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY)
+      az_key_split(s0, s1, (uint32_t)b, &k0, &k1);
+    int parent, action, nxt, depth;
+    az_simulate_lane<AMAX, KMAX>(c, l, b, sim, k0, k1, parent, action, nxt, depth);
+    parent_out[b] = parent;
+    action_out[b] = action;
+    next_out[b] = nxt == AZ_UNVISITED ? sim + 1 : nxt;
+    depth_sum = depth;
+  }
+  az_add_depth(sum_depth, depth_sum);
+}
+
+extern "C" int az_simulate(const az_search_desc* d, const az_tree* t, const az_search_inputs* in,
+                           int32_t sim, int32_t* parent, int32_t* action, int32_t* next,
+                           int64_t* sum_depth, void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (int rc = az_check_inputs(d, in)) return rc;
+  if (sim < 0 || sim >= d->S) return az_fail(AZ_ERR_INVALID, "sim=%d outside [0,%d)", sim, d->S);
+  if (!parent || !action || !next) return az_fail(AZ_ERR_INVALID, "null output arrays");
+  // simulate_key of simulation `sim`: walk the split(rng, 3) chain on the host
+  uint32_t r0 = d->key[0], r1 = d->key[1], s0 = 0, s1 = 0;
+  for (int i = 0; i <= sim; ++i) {
+    uint32_t n0, n1;
+    az_key_split(r0, r1, 1u, &s0, &s1);
+    az_key_split(r0, r1, 0u, &n0, &n1);
+    r0 = n0;
+    r1 = n1;
+  }
+  SearchCtx c{*d, *in};
+  return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+    k_simulate<AMAX, KMAX><<<dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+        c, *t, sim, s0, s1, parent, action, next, reinterpret_cast<unsigned long long*>(sum_depth));
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  });
+}
+
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(64) void k_expand_backward(
+    az_search_desc d, az_tree t, const int32_t* __restrict__ parent,
+    const int32_t* __restrict__ action, const int32_t* __restrict__ next,
+    const float* __restrict__ prior_logits, const float* __restrict__ value,
+    const float* __restrict__ reward, const float* __restrict__ discount) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  const int A = d.A, K = d.K;
+  Lane<AMAX, KMAX> l(t, b, d.S + 1, d.A, d.K);
+  float logits[AMAX], val[KMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < d.A) logits[a] = prior_logits[(size_t)b * d.A + a];
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k)
+    if (k < d.K) val[k] = value[(size_t)b * d.K + k];
+  const int node = next[b];
+  az_expand_write<AMAX, KMAX>(l, parent[b], action[b], node, logits, val, reward[b], discount[b]);
+  az_backward_lane<AMAX, KMAX>(l, node);
+}
+
+extern "C" int az_expand_backward(const az_search_desc* d, const az_tree* t, const int32_t* parent,
+                                  const int32_t* action, const int32_t* next,
+                                  const float* prior_logits, const float* value,
+                                  const float* reward, const float* discount, void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (!parent || !action || !next || !prior_logits || !value || !reward || !discount)
+    return az_fail(AZ_ERR_INVALID, "null expand arrays");
+  return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+    k_expand_backward<AMAX, KMAX><<<dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+        *d, *t, parent, action, next, prior_logits, value, reward, discount);
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  });
+}
+
+// mctx_dist/_src/policies.py:321-343
+template <int AMAX, int KMAX>
+__global__ void k_epilogue_gumbel(az_search_desc d, az_tree t, const float* __restrict__ root_logits,
+                                  const float* __restrict__ gumbel, const float* __restrict__ invalid,
+                                  int32_t* __restrict__ action, float* __restrict__ weights) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  const int A = d.A;
+  Lane<AMAX, KMAX> l(t, b, d.S + 1, A, d.K);
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, AZ_ROOT, r);
+  int32_t considered_visit = r.vis[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A && r.vis[a] > considered_visit) considered_visit = r.vis[a];
+  float cq[AMAX], score[AMAX], rl[AMAX], x[AMAX], w[AMAX];
+  az_qtransform<AMAX, KMAX>(l, d, AZ_ROOT, r, cq);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) rl[a] = root_logits[(size_t)b * A + a];
+  az_score_considered<AMAX>(considered_visit, gumbel + (size_t)b * A, rl, cq, r.vis, A, score);
+  const float* inv = invalid ? invalid + (size_t)b * A : nullptr;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A && inv && inv[a] != 0.0f) score[a] = -AZ_INF;
+  action[b] = az_argmax<AMAX>(score, A);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) x[a] = rl[a] + cq[a];
+  if (inv) {
+    float mx = x[0];
+AZ_UNROLL_A
+    for (int a = 1; a < AZ_TRIP_A; ++a)
+      if (a < A) mx = az_maxf(mx, x[a]);
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        x[a] = x[a] - mx;
+        if (inv[a] != 0.0f) x[a] = -AZ_FLT_MAX;
+      }
+  }
+  az_softmax<AMAX>(x, A, w);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) weights[(size_t)b * A + a] = w[a];
+}
+
+extern "C" int az_epilogue_gumbel(const az_search_desc* d, const az_tree* t,
+                                  const float* root_logits, const float* root_gumbel,
+                                  const float* invalid, int32_t* action, float* action_weights,
+                                  void* stream) {
+  if (int rc = az_check_desc(d, t)) return rc;
+  if (!root_logits || !root_gumbel || !action || !action_weights)
+    return az_fail(AZ_ERR_INVALID, "bad gumbel epilogue arguments");
+  return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+    k_epilogue_gumbel<AMAX, KMAX><<<dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+        *d, *t, root_logits, root_gumbel, invalid, action, action_weights);
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  });
+}
+

@@ -1,0 +1,390 @@
+"""GPU parity: the HIP path (through the C ABI) against the plain-C CPU checker.
+
+Bar: selected actions, visit counts and node/parent/child indices bit-exact; on
+top of that the float arrays are required to be bit-identical too, because both
+sides evaluate the same numerics specification (az_math.h) -- a stricter bar
+than the 1e-5 relative tolerance the task allows for Q-values and
+action_weights.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import runners
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import gpu_util
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return gpu_util
+
+
+# ---------------------------------------------------------------- numerics spec
+@pytest.mark.parametrize("fn,lo,hi", [("exp", -110.0, 90.0), ("log", 0.0, 1e30), ("sin", -40.0, 40.0),
+                                      ("cos", -40.0, 40.0), ("swish", -100.0, 100.0),
+                                      ("sqrt", 0.0, 1e30), ("rcp", -1e3, 1e3)])
+def test_numerics_spec_host_device_bits(hip, oracle, fn, lo, hi):
+    """Every elementary function gives the same bits on the host and on gfx950."""
+    from alphazero_amd import _native as nat
+    rng = np.random.default_rng(0)
+    x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
+    if fn in ("log", "sqrt"):
+        x = np.exp(rng.uniform(-100, 69, 1 << 20)).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38]
+    xd = hip.dev(x)
+    yd = torch.empty_like(xd)
+    code = oracle._MATH_FN[fn]
+    nat.check(nat.lib().az_math_apply(code, x.size, nat.ptr(xd), nat.ptr(yd), nat.stream_ptr()))
+    y = yd.cpu().numpy()
+    ref = oracle.math_apply(fn, x)
+    same = (y.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(y) & np.isnan(ref))
+    assert same.all(), (fn, x[~same][:5], y[~same][:5], ref[~same][:5])
+
+
+def test_gumbel_from_bits_host_device(hip, oracle):
+    from alphazero_amd import _native as nat
+    bits = np.random.default_rng(1).integers(0, 2 ** 32, 1 << 18, dtype=np.uint64).astype(np.uint32)
+    bits[:3] = [0, 0xffffffff, 1 << 9]
+    xd = hip.dev(bits.view(np.float32))
+    yd = torch.empty_like(xd)
+    nat.check(nat.lib().az_math_apply(7, bits.size, nat.ptr(xd), nat.ptr(yd), nat.stream_ptr()))
+    ref = oracle.math_apply("gumbel_from_bits", bits.view(np.float32))
+    assert np.array_equal(yd.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_threefry_device(hip, oracle):
+    from alphazero_amd import _native as nat
+    from alphazero_amd import prng
+    key = np.array([[0, 0], [0xffffffff, 0xffffffff], [0x13198a2e, 0x03707344]], np.uint32)
+    ctr = np.array([[0, 0], [0xffffffff, 0xffffffff], [0x243f6a88, 0x85a308d3]], np.uint32)
+    kd, cd = hip.dev(key.view(np.int32)), hip.dev(ctr.view(np.int32))
+    od = torch.empty_like(kd)
+    nat.check(nat.lib().az_threefry(3, nat.ptr(kd), nat.ptr(cd), nat.ptr(od), nat.stream_ptr()))
+    out = od.cpu().numpy().view(np.uint32)
+    expect = np.array([[0x6b200159, 0x99ba4efe], [0x1cb996fc, 0xbb002be7],
+                       [0xc4923a9c, 0x483df7a0]], np.uint32)
+    assert np.array_equal(out, expect)
+    assert np.array_equal(out, oracle.threefry(key, ctr))
+    # host key derivation agrees with the device / C implementation
+    for k in ((0, 0), (123, 456)):
+        assert [tuple(int(v) for v in r) for r in oracle.key_split(np.array(k, np.uint32), 5)] == \
+            prng.split(k, 5)
+
+
+# ---------------------------------------------------------------- tree kernels
+INJECTED_CASES = [
+    dict(variant="gumbel", B=64, S=32, A=2, K=1),
+    dict(variant="gumbel", B=37, S=16, A=4, K=1),
+    dict(variant="gumbel", B=16, S=24, A=6, K=3, with_invalid=True),
+    dict(variant="gumbel", B=16, S=24, A=3, K=1, max_depth=3),
+    dict(variant="gumbel", B=16, S=16, A=4, K=1, qt_kwargs=dict(use_mixed_value=False)),
+    dict(variant="gumbel", B=8, S=16, A=12, K=1, qt_kwargs=dict(rescale_values=False, value_scale=0.5)),
+    dict(variant="gumbel", B=8, S=20, A=40, K=1),
+    dict(variant="muzero", B=64, S=32, A=2, K=1),
+    dict(variant="muzero", B=16, S=24, A=3, K=2, with_invalid=True),
+    dict(variant="muzero", B=16, S=24, A=3, K=1, max_depth=2),
+    dict(variant="muzero", B=8, S=16, A=4, K=1, qtransform="min_max",
+         qt_kwargs=dict(min_value=-1.0, max_value=2.0)),
+    dict(variant="muzero", B=8, S=16, A=20, K=12),
+    dict(variant="sampled", B=32, S=16, A=4, K=8),
+    dict(variant="sampled", B=16, S=24, A=3, K=1, with_invalid=True),
+]
+_ids = lambda k: "-".join(f"{a}{b}" for a, b in k.items())  # noqa: E731
+
+
+def _case(kw, seed=7):
+    kw = dict(kw)
+    return runners.synthetic_case(kw.pop("variant"), kw.pop("B"), kw.pop("S"), kw.pop("A"),
+                                  kw.pop("K"), seed=seed, **kw)
+
+
+@pytest.mark.parametrize("kw", INJECTED_CASES, ids=_ids)
+def test_persistent_tree_kernel_vs_oracle(hip, kw):
+    case = _case(kw)
+    ref = runners.run_policy_c(case)
+    out = hip.run_policy_hip(case, "persistent")
+    hip.assert_same(out, ref)
+
+
+@pytest.mark.parametrize("kw", [INJECTED_CASES[i] for i in (0, 2, 3, 8, 12)], ids=_ids)
+def test_callback_path_vs_oracle(hip, kw):
+    case = _case(kw, seed=9)
+    ref = runners.run_policy_c(case)
+    out = hip.run_policy_hip(case, "callback")
+    hip.assert_same(out, ref)
+    # the caller-owned embeddings were gathered from the parent and scattered to the child
+    t = out["_tree"]
+    emb = t.embeddings.cpu().numpy()
+    par = out["parents"]
+    for b in range(case["B"]):
+        for n in range(1, case["S"] + 1):
+            if par[b, n] >= 0 and case.get("max_depth") is None:
+                assert emb[b, n] == emb[b, par[b, n]] + 1
+
+
+def test_golden_fixture(hip):
+    """Committed golden vectors (generated by tests/golden/make_golden.py from the C checker)."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "mcts_golden.npz")
+    g = np.load(path)
+    for name in ("gumbel", "muzero", "sampled"):
+        case = runners.synthetic_case(name, B=8, S=16, A=3, K=2 if name != "gumbel" else 1, seed=101)
+        out = hip.run_policy_hip(case, "persistent")
+        for f in hip.INT_FIELDS + hip.FLT_FIELDS + ("action", "action_weights"):
+            assert np.array_equal(out[f], g[f"{name}/{f}"].reshape(out[f].shape)), (name, f)
+
+
+# ---------------------------------------------------------------- model pieces
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"])
+def test_forward_and_recurrent_step_vs_oracle(hip, oracle, env_id):
+    import alphazero_amd as mctx
+    rng = np.random.default_rng(5)
+    case = runners.synthetic_case("gumbel", B=50, S=1, K=3, seed=5, env_id=env_id, random_bias=True)
+    model = case["model"]
+    fm = hip.make_model(model)
+    md = oracle.make_model(env_id, model["policy_layers"], model["value_layers"], model["mean"],
+                           model["std"])
+    # forward
+    obs = oracle.env_reset(env_id, rng.integers(0, 2 ** 32, (50, 2), dtype=np.uint64).astype(np.uint32))["obs"]
+    lg, val = fm.forward(hip.dev(obs))
+    rl, rv = oracle.forward(md, obs)
+    assert np.array_equal(lg.cpu().numpy(), rl) and np.array_equal(val.cpu().numpy(), rv)
+    # recurrent step over a few steps, including states far past termination
+    state = rng.uniform(-3, 3, (50, 4)).astype(np.float32)
+    time = rng.integers(0, 10, 50).astype(np.int32)
+    if env_id == "MountainCar-v0":
+        state[:, 0] = rng.uniform(-1.2, 0.6, 50)
+        state[:, 1] = rng.uniform(-0.07, 0.07, 50)
+        state[:, 2:] = 0
+    time[0] = 4999 if env_id != "CartPole-v1" else 49999
+    frf = mctx.FusedRecurrentFn(fm)
+    emb = {"state": hip.dev(state), "time": hip.dev(time)}
+    for _ in range(4):
+        action = rng.integers(0, fm.num_actions, 50).astype(np.int32)
+        out, emb = frf((), None, hip.dev(action), emb)
+        o = oracle.env_step(env_id, state, time, action)
+        state, time = o["state"], o["time"]
+        rl, rv = oracle.forward(md, o["obs"])
+        disc = np.float32(0.99) * np.where(o["truncated"] != 0, np.float32(1), np.float32(1) - o["terminated"])
+        assert np.array_equal(emb["state"].cpu().numpy(), state)
+        assert np.array_equal(emb["time"].cpu().numpy(), time)
+        assert np.array_equal(out.reward.cpu().numpy(), o["reward"])
+        assert np.array_equal(out.discount.cpu().numpy(), disc.astype(np.float32))
+        assert np.array_equal(out.prior_logits.cpu().numpy(), rl)
+        assert np.array_equal(out.value.cpu().numpy(), rv)
+
+
+FUSED_CASES = [
+    ("CartPole-v1", "gumbel", 40, 16, 1, {}),
+    ("CartPole-v1", "muzero", 16, 12, 1, {}),
+    ("CartPole-v1", "gumbel", 16, 12, 1, dict(qt_kwargs=dict(use_mixed_value=False))),
+    ("MountainCar-v0", "muzero", 16, 12, 1, {}),
+    ("Acrobot-v1", "gumbel", 16, 12, 1, {}),
+    ("Acrobot-v1", "sampled", 16, 12, 8, {}),
+    ("CartPole-v1", "gumbel", 16, 20, 1, dict(max_depth=3)),
+]
+
+
+@pytest.mark.parametrize("env_id,variant,B,S,K,extra", FUSED_CASES,
+                         ids=[f"{c[0]}-{c[1]}-B{c[2]}-S{c[3]}-K{c[4]}" + ("-x" if c[5] else "")
+                              for c in FUSED_CASES])
+def test_fused_search_vs_oracle(hip, env_id, variant, B, S, K, extra):
+    case = runners.synthetic_case(variant, B=B, S=S, K=K, seed=13, env_id=env_id, random_bias=True,
+                                  **extra)
+    ref = runners.run_policy_c(case)
+    out = hip.run_policy_hip(case, "persistent")
+    hip.assert_same(out, ref)
+    assert np.array_equal(out["emb_state"], ref["emb_state"])
+    assert np.array_equal(out["emb_time"], ref["emb_time"])
+
+
+def test_fused_equals_callback_path(hip):
+    """The fused persistent kernel and the per-simulation callback path build the same tree."""
+    case = runners.synthetic_case("gumbel", B=24, S=10, K=1, seed=17, env_id="CartPole-v1")
+    a = hip.run_policy_hip(case, "persistent")
+    b = hip.run_policy_hip(case, "callback")
+    hip.assert_same(a, b)
+
+
+# ---------------------------------------------------------------- full size, properties
+def check_invariants(out, S):
+    nv, cv, ci = out["node_visits"], out["children_visits"], out["children_index"]
+    par, afp = out["parents"], out["action_from_parent"]
+    B, N = nv.shape
+    assert (nv[:, 0] == S + 1).all()
+    assert (cv[:, 0].sum(-1) == S).all()
+    assert (par[:, 1:] >= 0).all() and (par[:, 1:] < np.arange(1, N)[None]).all()
+    lanes = np.arange(B)[:, None].repeat(N - 1, 1)
+    nodes = np.arange(1, N)[None].repeat(B, 0)
+    assert (ci[lanes, par[:, 1:], afp[:, 1:]] == nodes).all()
+    assert (nv[:, 1:] == 1 + cv[:, 1:].sum(-1)).all()
+
+
+def test_full_size_tree_kernel_properties(hip):
+    """BASELINE config sizes (B=4096, S=64): structural invariants, the A=2 sequential
+    halving split (32, 32), and equality with the CPU checker."""
+    case = runners.synthetic_case("gumbel", B=4096, S=64, A=2, K=1, seed=21)
+    out = hip.run_policy_hip(case, "persistent")
+    check_invariants(out, 64)
+    assert (out["children_visits"][:, 0] == 32).all()
+    ref = runners.run_policy_c(case)
+    hip.assert_same(out, ref)
+
+
+def test_full_size_fused_properties(hip):
+    case = runners.synthetic_case("gumbel", B=4096, S=64, K=1, seed=23, env_id="CartPole-v1")
+    out = hip.run_policy_hip(case, "persistent")
+    check_invariants(out, 64)
+    assert (out["children_visits"][:, 0] == 32).all()
+    w = out["action_weights"]
+    np.testing.assert_allclose(w.sum(-1), 1.0, rtol=1e-6)
+    # idempotence: a second run on the same inputs gives the same bits
+    out2 = hip.run_policy_hip(case, "persistent")
+    hip.assert_same(out, out2)
+    # lane independence: the first 64 lanes alone give the same trees
+    ref = runners.run_policy_c({**case, "B": 64, **{k: case[k][:64] for k in
+                                ("prior_logits", "value", "root_gumbel", "root_state", "root_time")}})
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS:
+        assert np.array_equal(out[f][:64], ref[f].reshape(out[f][:64].shape)), f
+
+
+# ---------------------------------------------------------------- device RNG paths
+def test_default_rng_paths_vs_oracle(hip, oracle):
+    """Without injected noise the device threefry streams equal the C checker's."""
+    import alphazero_amd as mctx
+    from alphazero_amd import prng
+    case = runners.synthetic_case("muzero", B=32, S=16, A=3, K=1, seed=31)
+    ev = {k: hip.dev(x) for k, x in case["evals"].items()}
+    rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"], ev["reward"], ev["discount"])
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"]),
+                             embedding=None)
+    key = (7, 11)
+    out = mctx.muzero_policy((), key, root, rf, 16, dirichlet_noise=hip.dev(case["dirichlet"]))
+    torch.cuda.synchronize()
+    rng_key, _, search_key = prng.split(key, 3)
+    cfg = oracle.make_cfg(32, 16, 3, 1, variant="muzero", noise_mode="threefry", key=search_key)
+    tree = oracle.alloc_tree(32, 16, 3, 1)
+    prior = oracle.root_muzero(case["prior_logits"], case["dirichlet"], 0.25)
+    oracle.tree_init(cfg, tree, prior, case["value"])
+    oracle.search_injected(cfg, tree, case["evals"])
+    action, weights = oracle.epilogue_visits(cfg, tree, 1.0, key=rng_key)
+    t = out.search_tree
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS:
+        assert np.array_equal(getattr(t, f).cpu().numpy(), tree[f]), f
+    assert np.array_equal(out.action.cpu().numpy(), action)
+    assert np.array_equal(out.action_weights.cpu().numpy(), weights)
+
+
+def test_gumbel_and_sampled_default_noise_vs_oracle(hip, oracle):
+    import alphazero_amd as mctx
+    from alphazero_amd import prng
+    case = runners.synthetic_case("gumbel", B=16, S=8, A=5, K=1, seed=33)
+    ev = {k: hip.dev(x) for k, x in case["evals"].items()}
+    rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"], ev["reward"], ev["discount"])
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"]),
+                             embedding=None)
+    out = mctx.gumbel_muzero_policy((), 42, root, rf, 8, gumbel_scale=0.5)
+    torch.cuda.synchronize()
+    _, gkey = prng.split(42, 2)
+    _, g = oracle.root_gumbel(case["prior_logits"], key=gkey, gumbel_scale=0.5)
+    assert np.array_equal(out.search_tree.extra_data.root_gumbel.cpu().numpy(), g)
+    # sampled: categorical draw counts from the device stream
+    case = runners.synthetic_case("sampled", B=16, S=8, A=5, K=1, seed=35, num_samples=16)
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"]),
+                             embedding=None)
+    ev = {k: hip.dev(x) for k, x in case["evals"].items()}
+    rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"], ev["reward"], ev["discount"])
+    out = mctx.sampled_muzero_policy((), 5, root, rf, 8, num_samples=16,
+                                     dirichlet_noise=hip.dev(case["dirichlet"]), tiebreak_noise="zero")
+    torch.cuda.synchronize()
+    _, skey, _, _ = prng.split(5, 4)
+    probs, counts = oracle.root_sampled(case["prior_logits"], case["dirichlet"], 0.25, None, 16, 1.0,
+                                        key=skey)
+    assert (counts.sum(-1) == 16).all()
+    assert np.array_equal(out.search_tree.children_prior_logits[:, 0].cpu().numpy(), probs)
+
+
+def test_dirichlet_statistics(hip):
+    from alphazero_amd import _native as nat
+    B, A = 20000, 4
+    out = torch.empty((B, A), device="cuda")
+    key = (C.c_uint32 * 2)(3, 9)
+    nat.check(nat.lib().az_dirichlet(B, A, 0.3, key, nat.ptr(out), nat.stream_ptr()))
+    x = out.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(x.sum(-1), 1.0, rtol=1e-5)
+    assert (x >= 0).all()
+    np.testing.assert_allclose(x.mean(0), 0.25, atol=0.01)
+    # Var = a0(1-a0)/(A*alpha+1) with a0 = 1/A
+    np.testing.assert_allclose(x.var(0), 0.25 * 0.75 / (A * 0.3 + 1), rtol=0.08)
+
+
+# ---------------------------------------------------------------- environment + actor glue
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"])
+def test_real_env_step_vs_oracle(hip, oracle, env_id):
+    import alphazero_amd as mctx
+    env = mctx.envs.make(env_id, episode_length=7)
+    st = env.reset(3, batch_size=33)
+    keys = oracle.key_split(np.array([0, 3], np.uint32), 33)
+    r = oracle.env_reset(env_id, keys)
+    assert np.array_equal(st.state.cpu().numpy(), r["state"])
+    assert np.array_equal(st.obs.cpu().numpy(), r["obs"])
+    ost = dict(state=r["state"], time=r["time"], obs=r["obs"], real_obs=r["obs"].copy(),
+               reward=np.zeros(33, np.float32), done=np.zeros(33, np.float32),
+               truncation=np.zeros(33, np.float32), steps=np.zeros(33, np.float32),
+               rng=np.stack([oracle.key_split(k, 1)[0] for k in keys]).astype(np.uint32))
+    assert np.array_equal(st.rng.cpu().numpy().view(np.uint32), ost["rng"])
+    rng = np.random.default_rng(2)
+    for step in range(20):
+        action = rng.integers(0, env.action_size, 33).astype(np.int32)
+        st = env.step(st, hip.dev(action))
+        ost = oracle.real_env_step(env_id, 7, ost, action)
+        for f in ("state", "time", "obs", "real_obs", "reward", "done", "truncation", "steps"):
+            assert np.array_equal(getattr(st, f).cpu().numpy(), ost[f]), (step, f)
+        assert np.array_equal(st.rng.cpu().numpy().view(np.uint32), ost["rng"])
+    assert ost["done"].sum() >= 0 and (ost["steps"] <= 7).all()
+
+
+def test_summary_and_actor_post_vs_oracle(hip, oracle):
+    import alphazero_amd as mctx
+    case = runners.synthetic_case("muzero", B=16, S=12, A=4, K=3, seed=41)
+    ref = runners.run_policy_c(case)
+    out = hip.run_policy_hip(case, "persistent")
+    cfg = runners.make_cfg(case)
+    tree = {f: ref[f] for f in runners.TREE_FIELDS}
+    s_ref = oracle.summary(cfg, tree)
+    s = out["_tree"].summary()
+    for f in ("visit_counts", "visit_probs", "value", "qvalues"):
+        assert np.array_equal(getattr(s, f).cpu().numpy(), s_ref[f]), f
+    q = out["_tree"].qvalues(0).cpu().numpy()
+    assert np.array_equal(q, s_ref["qvalues"])
+    for det in (False, True):
+        a, sv, lp = mctx.actor_post(out["_tree"], out["_out"].action_weights, out["_out"].action,
+                                    hip.dev(case["prior_logits"]), deterministic=det)
+        ra, rsv, rlp = oracle.actor_post(cfg, tree, ref["action_weights"], ref["action"], det,
+                                         case["prior_logits"])
+        assert np.array_equal(a.cpu().numpy(), ra)
+        assert np.array_equal(sv.cpu().numpy(), rsv)
+        assert np.array_equal(lp.cpu().numpy(), rlp)
+
+
+def test_scalar_value_layout(hip):
+    """Root value given as [B] (the layout of mctx/_src) -> value arrays without the atom axis."""
+    import alphazero_amd as mctx
+    case = runners.synthetic_case("gumbel", B=8, S=8, A=3, K=1, seed=43)
+    ref = runners.run_policy_c(case)
+    ev = {k: hip.dev(x) for k, x in case["evals"].items()}
+    rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"][..., 0], ev["reward"], ev["discount"])
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]),
+                             value=hip.dev(case["value"][:, 0]), embedding=None)
+    out = mctx.gumbel_muzero_policy((), 0, root, rf, 8, root_gumbel=hip.dev(case["root_gumbel"]))
+    t = out.search_tree
+    assert t.node_values.shape == (8, 9) and t.children_values.shape == (8, 9, 3)
+    assert np.array_equal(t.node_values.cpu().numpy(), ref["node_values"][..., 0])
+    assert np.array_equal(t.children_values.cpu().numpy(), ref["children_values"][..., 0])
+    s = t.summary()
+    assert s.value.shape == (8,) and s.qvalues.shape == (8, 3)
