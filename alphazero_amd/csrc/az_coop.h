@@ -1,0 +1,313 @@
+// az_coop.h -- cooperative (16 threads per lane) form of the tree search.
+//
+// The literal search walks root -> leaf re-evaluating the selection rule at every
+// level (d dependent round trips of loads + exp/div arithmetic per simulation) and
+// then walks leaf -> root again for the backup.  The selection at a node depends only
+// on that node's own statistics, and those change only when the node lies on a
+// backup path.  So this form keeps, per node, the action the rule currently selects
+// together with the child it leads to (`sel`, in LDS), and restructures a simulation
+// as
+//   1. chase   : one thread per lane follows `sel` from the root -- one LDS read per
+//                level -- and records the path;
+//   2. evaluate: the caller's recurrent_fn (injected arrays, or env + MLP);
+//   3. update  : the 16 threads of the lane take one path node each: load the node's
+//                row (one round trip, all nodes in parallel), recompute the value
+//                chain from the leaf down to their node, apply the backup to their
+//                node, and re-evaluate the selection rule on the updated row.
+// Every floating-point operation is the same, on the same operands and in the same
+// order, as in the literal form (az_device.h), so the resulting tree is bit-identical.
+//
+// Applicability: the selection must not depend on per-visit randomness (Gumbel
+// variant, or PUCT with the tie-break noise disabled), A <= 8, K <= 8, N <= 65535.
+#ifndef AZ_COOP_H_
+#define AZ_COOP_H_
+
+#include "az_device.h"
+
+#define AZ_GROUP 16        // threads per lane
+#define AZ_WG_LANES 16     // lanes per workgroup
+#define AZ_TREE_THREADS (AZ_GROUP * AZ_WG_LANES)
+
+// Words of LDS per lane: sel[N], edge_r[N], edge_d[N], path[S+1], pr[S], pd[S], hdr[8].
+__host__ __device__ inline int az_coop_lane_words(int S) { return 6 * S + 12; }
+
+struct CoopLds {
+  int32_t* sel;   // [N]   (action << 16) | (child + 1) currently selected at each node
+  float* edge_r;  // [N]   reward of the edge leading INTO each node
+  float* edge_d;  // [N]   discount of that edge
+  int32_t* path;  // [S+1] node | action << 16 per path position
+  float* pr;      // [S]   edge reward by path position
+  float* pd;      // [S]   edge discount by path position
+  int32_t* hdr;   // [8]   depth, new node, parent, action, reward bits, discount bits
+  AZ_DEV CoopLds(float* base, int lane, int S) {
+    float* p = base + (size_t)lane * az_coop_lane_words(S);
+    const int N = S + 1;
+    sel = reinterpret_cast<int32_t*>(p);
+    edge_r = p + N;
+    edge_d = p + 2 * N;
+    path = reinterpret_cast<int32_t*>(p + 3 * N);
+    pr = p + 4 * N;
+    pd = p + 4 * N + S;
+    hdr = reinterpret_cast<int32_t*>(p + 4 * N + 2 * S);
+  }
+};
+
+// Every per-node word of one node, in registers.
+template <int AMAX, int KMAX>
+struct FullRow {
+  int32_t nv;
+  int32_t cidx[AMAX], vis[AMAX];
+  float logits[AMAX], rew[AMAX], disc[AMAX];
+  float cval[AMAX][KMAX];
+  float raw[KMAX], nval[KMAX];
+};
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_load_full_row(const Lane<AMAX, KMAX>& l, int node, FullRow<AMAX, KMAX>& r) {
+  const int A = l.A, K = l.K;
+  r.nv = l.nv[node];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      r.cidx[a] = l.cidx[node * A + a];
+      r.vis[a] = l.cvis[node * A + a];
+      r.logits[a] = l.clog[node * A + a];
+      r.rew[a] = l.crew[node * A + a];
+      r.disc[a] = l.cdisc[node * A + a];
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) r.cval[a][k] = l.cval[((size_t)node * A + a) * K + k];
+    }
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k)
+    if (k < K) {
+      r.raw[k] = l.raw[(size_t)node * K + k];
+      r.nval[k] = l.nval[(size_t)node * K + k];
+    }
+}
+
+// The selection inputs of a row held in registers; same arithmetic as az_load_row.
+template <int AMAX, int KMAX>
+AZ_DEV void az_node_row(const FullRow<AMAX, KMAX>& f, int A, int K, NodeRow<AMAX>& r) {
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      r.vis[a] = f.vis[a];
+      r.logits[a] = f.logits[a];
+      float s = 0.0f;
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) s = s + (f.rew[a] + f.disc[a] * f.cval[a][k]);
+      r.q[a] = s / (float)K;
+    }
+  float sv = 0.0f, sr = 0.0f;
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k)
+    if (k < K) {
+      sv = sv + f.nval[k];
+      sr = sr + f.raw[k];
+    }
+  r.vmean = sv / (float)K;
+  r.rawmean = sr / (float)K;
+  r.node_visit = f.nv;
+}
+
+// The action the search's selection rule picks at a node (root: depth 0).
+template <int AMAX>
+AZ_DEV int az_select_cached(const SearchCtx& c, int A, int b, bool root, const NodeRow<AMAX>& r) {
+  if (c.d.variant == AZ_VARIANT_GUMBEL)
+    return root ? az_select_gumbel_root<AMAX>(c, A, b, r) : az_select_gumbel_interior<AMAX>(c, A, r);
+  float noise[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
+  return az_select_puct<AMAX>(c, A, b, root ? 0 : 1, r, noise);
+}
+
+AZ_DEV int32_t az_pack_sel(int action, int child) { return (action << 16) | (child + 1); }
+
+// Before the first simulation: selection at the root of the fresh tree.
+template <int AMAX, int KMAX>
+AZ_DEV void az_coop_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b) {
+  const int A = l.A;
+  FullRow<AMAX, KMAX> f;
+  NodeRow<AMAX> r;
+  az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
+  az_node_row<AMAX, KMAX>(f, A, l.K, r);
+  const int a = az_select_cached<AMAX>(c, A, b, true, r);
+  int child = AZ_UNVISITED;
+AZ_UNROLL_A
+  for (int i = 0; i < AZ_TRIP_A; ++i)
+    if (i == a) child = f.cidx[i];
+  s.sel[AZ_ROOT] = az_pack_sel(a, child);
+}
+
+// Step 1 (one thread per lane): follow the cached selections from the root
+// (search.py:127-187) and record the path.  Returns the depth of the expanded node.
+AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
+  int node = AZ_ROOT, dep = 0, act, nxt;
+  for (;;) {
+    const int32_t e = s.sel[node];
+    act = e >> 16;
+    nxt = (e & 0xffff) - 1;
+    s.path[dep] = node | (act << 16);
+    if (nxt >= 0) {
+      s.pr[dep] = s.edge_r[nxt];
+      s.pd[dep] = s.edge_d[nxt];
+    }
+    dep += 1;
+    if (nxt < 0 || dep >= max_depth) break;
+    node = nxt;
+  }
+  s.hdr[0] = dep;
+  s.hdr[1] = nxt < 0 ? sim + 1 : nxt;  // search.py:97-99
+  s.hdr[2] = node;
+  s.hdr[3] = act;
+  return dep;
+}
+
+// Largest path depth over the workgroup's lanes (uniform across the workgroup).
+AZ_DEV int az_coop_max_depth(float* lds_base, int S) {
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < AZ_WG_LANES; ++i) {
+    const int d = CoopLds(lds_base, i, S).hdr[0];
+    m = d > m ? d : m;
+  }
+  return m;
+}
+
+// Step 3 for path position p (0 = root ... dep-1 = parent, dep = the expanded node):
+// phase A loads what the position needs, phase B (after a workgroup barrier) applies
+// expand (search.py:231-244, 304-342) and backward (search.py:265-286) to the node
+// at that position and refreshes its cached selection.
+template <int AMAX, int KMAX>
+struct CoopPos {
+  FullRow<AMAX, KMAX> row;
+  float child_old[KMAX];
+  int32_t child_cnt;
+  int node, act;
+};
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_coop_load(const Lane<AMAX, KMAX>& l, const CoopLds& s, int p, int dep, int newn,
+                         CoopPos<AMAX, KMAX>& P) {
+  const int K = l.K;
+  if (p < dep) {
+    const int32_t e = s.path[p];
+    P.node = e & 0xffff;
+    P.act = e >> 16;
+  } else {
+    P.node = newn;
+    P.act = 0;
+  }
+  az_load_full_row<AMAX, KMAX>(l, P.node, P.row);
+  P.child_cnt = 0;
+  if (p + 1 < dep) {
+    const int child = s.path[p + 1] & 0xffff;
+    P.child_cnt = l.nv[child];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) P.child_old[k] = l.nval[(size_t)child * K + k];
+  }
+}
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_coop_apply(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b,
+                          int p, int dep, int newn, int parent, int action,
+                          const float* ev_logits, const float* ev_value, float reward,
+                          float discount, CoopPos<AMAX, KMAX>& P) {
+  const int A = l.A, K = l.K;
+  FullRow<AMAX, KMAX>& f = P.row;
+  const int node = P.node;
+  if (p == dep) {
+    // the evaluated node (update_tree_node, search.py:304-342)
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        f.logits[a] = ev_logits[a];
+        l.clog[node * A + a] = f.logits[a];
+      }
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) {
+        f.raw[k] = ev_value[k];
+        f.nval[k] = ev_value[k];
+        l.raw[(size_t)node * K + k] = f.raw[k];
+        l.nval[(size_t)node * K + k] = f.nval[k];
+      }
+    f.nv = f.nv + 1;
+    l.nv[node] = f.nv;
+    l.par[node] = parent;
+    l.afp[node] = action;
+    s.edge_r[node] = reward;
+    s.edge_d[node] = discount;
+  } else {
+    const int act = P.act;
+    if (p == dep - 1) {
+      // the edge parent -> evaluated node (search.py:235-241)
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a == act) {
+          f.cidx[a] = newn;
+          f.rew[a] = reward;
+          f.disc[a] = discount;
+        }
+      l.cidx[node * A + act] = newn;
+      l.crew[node * A + act] = reward;
+      l.cdisc[node * A + act] = discount;
+    }
+    // backward (search.py:265-286): value chain from the leaf down to this node
+    float lv[KMAX], child_new[KMAX];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) lv[k] = ev_value[k];
+    for (int q = dep - 1; q > p; --q) {
+      const float r = q == dep - 1 ? reward : s.pr[q];
+      const float dsc = q == dep - 1 ? discount : s.pd[q];
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) lv[k] = r + dsc * lv[k];
+    }
+    const float cnt_child = (float)P.child_cnt;
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K)
+        child_new[k] = p + 1 == dep ? ev_value[k]
+                                    : (P.child_old[k] * cnt_child + lv[k]) / (cnt_child + 1.0f);
+    const float r = p == dep - 1 ? reward : s.pr[p];
+    const float dsc = p == dep - 1 ? discount : s.pd[p];
+    const float cnt = (float)f.nv;
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) {
+        lv[k] = r + dsc * lv[k];
+        f.nval[k] = (f.nval[k] * cnt + lv[k]) / (cnt + 1.0f);
+        l.nval[(size_t)node * K + k] = f.nval[k];
+        l.cval[((size_t)node * A + act) * K + k] = child_new[k];
+      }
+    int32_t newvis = 0;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a == act) {
+AZ_UNROLL_K
+        for (int k = 0; k < AZ_TRIP_K; ++k)
+          if (k < K) f.cval[a][k] = child_new[k];
+        f.vis[a] = f.vis[a] + 1;
+        newvis = f.vis[a];
+      }
+    l.cvis[node * A + act] = newvis;
+    f.nv = f.nv + 1;
+    l.nv[node] = f.nv;
+  }
+  // refresh the cached selection of this node
+  NodeRow<AMAX> r;
+  az_node_row<AMAX, KMAX>(f, A, K, r);
+  const int best = az_select_cached<AMAX>(c, A, b, p == 0, r);
+  int child = AZ_UNVISITED;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a == best) child = f.cidx[a];
+  s.sel[node] = az_pack_sel(best, child);
+}
+
+#endif  // AZ_COOP_H_

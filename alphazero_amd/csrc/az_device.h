@@ -99,7 +99,21 @@ struct NodeRow {
   int32_t vis[AMAX];
   float logits[AMAX];
   float q[AMAX];  // mean over atoms of reward + discount * child value
+  float vmean;    // mean over atoms of node_values[node]
+  float rawmean;  // mean over atoms of raw_values[node]
+  int32_t node_visit;
 };
+
+template <int AMAX, int KMAX>
+AZ_DEV float az_mean_atoms(const float* x, int K) {
+  float s = 0.0f;
+  if (KMAX == 1) {
+    s = s + x[0];
+  } else {
+    for (int k = 0; k < K; ++k) s = s + x[k];
+  }
+  return s / (float)K;
+}
 
 // mctx_dist/_src/tree.py:142-147 + the mean over atoms every qtransform applies first.
 template <int AMAX, int KMAX>
@@ -121,25 +135,16 @@ AZ_UNROLL_A
       r.q[a] = s / (float)K;
     }
   }
-}
-
-template <int AMAX, int KMAX>
-AZ_DEV float az_mean_atoms(const float* x, int K) {
-  float s = 0.0f;
-  if (KMAX == 1) {
-    s = s + x[0];
-  } else {
-    for (int k = 0; k < K; ++k) s = s + x[k];
-  }
-  return s / (float)K;
+  r.vmean = az_mean_atoms<AMAX, KMAX>(l.nval + (size_t)node * K, K);
+  r.rawmean = az_mean_atoms<AMAX, KMAX>(l.raw + (size_t)node * K, K);
+  r.node_visit = l.nv[node];
 }
 
 // mctx_dist/_src/qtransforms.py:54-87
-template <int AMAX, int KMAX>
-AZ_DEV void az_qt_parent_siblings(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
-                                  const NodeRow<AMAX>& r, float (&out)[AMAX]) {
-  const int A = l.A;
-  float v = az_mean_atoms<AMAX, KMAX>(l.nval + (size_t)node * l.K, l.K);
+template <int AMAX>
+AZ_DEV void az_qt_parent_siblings(const az_search_desc& d, int A, const NodeRow<AMAX>& r,
+                                  float (&out)[AMAX]) {
+  float v = r.vmean;
   float lo = r.vis[0] > 0 ? r.q[0] : v;
   float hi = lo;
 AZ_UNROLL_A
@@ -161,10 +166,9 @@ AZ_UNROLL_A
 }
 
 // mctx_dist/_src/qtransforms.py:24-51
-template <int AMAX, int KMAX>
-AZ_DEV void az_qt_min_max(const Lane<AMAX, KMAX>& l, const az_search_desc& d,
-                          const NodeRow<AMAX>& r, float (&out)[AMAX]) {
-  const int A = l.A;
+template <int AMAX>
+AZ_DEV void az_qt_min_max(const az_search_desc& d, int A, const NodeRow<AMAX>& r,
+                          float (&out)[AMAX]) {
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) {
@@ -174,11 +178,10 @@ AZ_UNROLL_A
 }
 
 // mctx_dist/_src/qtransforms.py:90-149, 152-198
-template <int AMAX, int KMAX>
-AZ_DEV void az_qt_completed_mix(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
-                                const NodeRow<AMAX>& r, float (&out)[AMAX]) {
-  const int A = l.A;
-  float raw = az_mean_atoms<AMAX, KMAX>(l.raw + (size_t)node * l.K, l.K);
+template <int AMAX>
+AZ_DEV void az_qt_completed_mix(const az_search_desc& d, int A, const NodeRow<AMAX>& r,
+                                float (&out)[AMAX]) {
+  float raw = r.rawmean;
   float value;
   if (d.use_mixed_value) {
     float probs[AMAX];
@@ -230,15 +233,15 @@ AZ_UNROLL_A
     if (a < A) out[a] = (visit_scale * d.value_scale) * cq[a];
 }
 
-template <int AMAX, int KMAX>
-AZ_DEV void az_qtransform(const Lane<AMAX, KMAX>& l, const az_search_desc& d, int node,
-                          const NodeRow<AMAX>& r, float (&out)[AMAX]) {
+template <int AMAX>
+AZ_DEV void az_qtransform(const az_search_desc& d, int A, const NodeRow<AMAX>& r,
+                          float (&out)[AMAX]) {
   if (d.qtransform == AZ_QT_PARENT_SIBLINGS)
-    az_qt_parent_siblings<AMAX, KMAX>(l, d, node, r, out);
+    az_qt_parent_siblings<AMAX>(d, A, r, out);
   else if (d.qtransform == AZ_QT_COMPLETED_MIX)
-    az_qt_completed_mix<AMAX, KMAX>(l, d, node, r, out);
+    az_qt_completed_mix<AMAX>(d, A, r, out);
   else
-    az_qt_min_max<AMAX, KMAX>(l, d, r, out);
+    az_qt_min_max<AMAX>(d, A, r, out);
 }
 
 // mctx_dist/_src/seq_halving.py:23-33
@@ -266,14 +269,11 @@ struct SearchCtx {
 };
 
 // mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled).
-template <int AMAX, int KMAX>
-AZ_DEV int az_select_puct(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, int node, int depth,
+template <int AMAX>
+AZ_DEV int az_select_puct(const SearchCtx& c, int A, int b, int depth, const NodeRow<AMAX>& r,
                           const float (&noise)[AMAX]) {
   const az_search_desc& d = c.d;
-  const int A = l.A;
-  NodeRow<AMAX> r;
-  az_load_row<AMAX, KMAX>(l, node, r);
-  int32_t node_visit = l.nv[node];
+  int32_t node_visit = r.node_visit;
   float pb_c = d.pb_c_init + az_logf((((float)node_visit + d.pb_c_base) + 1.0f) / d.pb_c_base);
   float probs[AMAX], value_score[AMAX], to_argmax[AMAX];
   if (d.variant == AZ_VARIANT_MUZERO) {
@@ -282,7 +282,7 @@ AZ_DEV int az_select_puct(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, 
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a) probs[a] = r.logits[a];
   }
-  az_qtransform<AMAX, KMAX>(l, d, node, r, value_score);
+  az_qtransform<AMAX>(d, A, r, value_score);
   float sq = az_sqrtf((float)node_visit);
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -298,14 +298,11 @@ AZ_UNROLL_A
 }
 
 // mctx_dist/_src/action_selection.py:148-200
-template <int AMAX, int KMAX>
-AZ_DEV int az_select_gumbel_root(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int b, int node) {
+template <int AMAX>
+AZ_DEV int az_select_gumbel_root(const SearchCtx& c, int A, int b, const NodeRow<AMAX>& r) {
   const az_search_desc& d = c.d;
-  const int A = l.A;
-  NodeRow<AMAX> r;
-  az_load_row<AMAX, KMAX>(l, node, r);
   float cq[AMAX], score[AMAX];
-  az_qtransform<AMAX, KMAX>(l, d, node, r, cq);
+  az_qtransform<AMAX>(d, A, r, cq);
   const float* inv = c.in.invalid_actions ? c.in.invalid_actions + (size_t)b * A : nullptr;
   float nvalid = 0.0f;
   int32_t sim_index = 0;
@@ -329,13 +326,10 @@ AZ_UNROLL_A
 }
 
 // mctx_dist/_src/action_selection.py:203-240, 256-277
-template <int AMAX, int KMAX>
-AZ_DEV int az_select_gumbel_interior(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int node) {
-  const int A = l.A;
-  NodeRow<AMAX> r;
-  az_load_row<AMAX, KMAX>(l, node, r);
+template <int AMAX>
+AZ_DEV int az_select_gumbel_interior(const SearchCtx& c, int A, const NodeRow<AMAX>& r) {
   float cq[AMAX], x[AMAX], probs[AMAX], to_argmax[AMAX];
-  az_qtransform<AMAX, KMAX>(l, c.d, node, r, cq);
+  az_qtransform<AMAX>(c.d, A, r, cq);
   int32_t sum_visits = 0;
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -361,6 +355,8 @@ AZ_DEV void az_simulate_lane(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int 
   int node = AZ_ROOT, depth = 0, act = -1, nxt = AZ_ROOT;
   for (;;) {
     node = nxt;
+    NodeRow<AMAX> r;
+    az_load_row<AMAX, KMAX>(l, node, r);
     if (d.variant != AZ_VARIANT_GUMBEL) {
       float noise[AMAX];
       if (d.noise_mode == AZ_NOISE_THREEFRY) {
@@ -386,11 +382,11 @@ AZ_UNROLL_A
 AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
       }
-      act = az_select_puct<AMAX, KMAX>(c, l, b, node, depth, noise);
+      act = az_select_puct<AMAX>(c, A, b, depth, r, noise);
     } else if (depth == 0) {
-      act = az_select_gumbel_root<AMAX, KMAX>(c, l, b, node);
+      act = az_select_gumbel_root<AMAX>(c, A, b, r);
     } else {
-      act = az_select_gumbel_interior<AMAX, KMAX>(c, l, node);
+      act = az_select_gumbel_interior<AMAX>(c, A, r);
     }
     nxt = l.cidx[node * A + act];
     depth += 1;

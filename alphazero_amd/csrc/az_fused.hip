@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "az_host.h"
+#include "az_coop.h"
 #include "az_envs.h"
 #include "az_mlp.h"
 
@@ -292,6 +293,73 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   if (tid < 64) az_add_depth(sum_depth, depth_sum);
 }
 
+
+// The fused search in the cooperative form (az_coop.h).  Threads 0..255 are the tree
+// threads (16 lanes x 16 threads); all AZ_MLP_WAVES waves run the networks.
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
+    SearchCtx c, az_tree t, ModelDev md, unsigned long long* sum_depth) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const az_search_desc& d = c.d;
+  const int A = d.A, K = d.K, S = d.S;
+  MlpLds s(lds, md.max_kp);
+  float* tree_lds = lds + az_mlp_lds_floats(md.max_kp);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool tree_thread = tid < AZ_TREE_THREADS;
+  const int ln = (tid >> 4) & (AZ_WG_LANES - 1), j = tid & (AZ_GROUP - 1);
+  const int b = blockIdx.x * AZ_WG_LANES + ln;
+  const bool active = tree_thread && b < d.B;
+  const bool leader = active && j == 0;
+  Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
+  CoopLds cs(tree_lds, ln, S);
+  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  if (tree_thread && j == 0) {
+    cs.hdr[0] = -1;
+    if (active) az_coop_init<AMAX, KMAX>(c, l, cs, b);
+  }
+  __syncthreads();
+  long long depth_sum = 0;
+  for (int sim = 0; sim < S; ++sim) {
+    EnvState st;
+    if (leader) {
+      depth_sum += az_coop_chase(cs, sim, d.max_depth);
+      const int parent = cs.hdr[2], action = cs.hdr[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
+      st.time = l.et[parent];
+      EnvOut o;
+      float reward, discount;
+      az_model_env_step(md, st, action, o, reward, discount);
+      cs.hdr[4] = (int32_t)az_f2u(reward);
+      cs.hdr[5] = (int32_t)az_f2u(discount);
+      az_store_obs(md, s, ln, o.obs);
+    }
+    __syncthreads();
+    az_forward_tile(md, s, wave, lane);
+    const int maxdep = az_coop_max_depth(tree_lds, S);
+    const int dep = cs.hdr[0], newn = cs.hdr[1], parent = cs.hdr[2], action = cs.hdr[3];
+    const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
+    if (leader) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = st.s[i];
+      l.et[newn] = st.time;
+    }
+    for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
+      const int p = j + it * AZ_GROUP;
+      const bool mine = active && p <= dep;
+      CoopPos<AMAX, KMAX> P;
+      if (mine) az_coop_load<AMAX, KMAX>(l, cs, p, dep, newn, P);
+      __syncthreads();
+      if (mine)
+        az_coop_apply<AMAX, KMAX>(c, l, cs, b, p, dep, newn, parent, action,
+                                  s.logits + ln * AZ_MAX_ACTIONS, s.value + ln * AZ_MAX_ATOMS,
+                                  reward, discount, P);
+      __syncthreads();
+    }
+  }
+  if (tree_thread) az_add_depth(sum_depth, depth_sum);
+}
+
 extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
                                const az_search_inputs* in, const az_model* m, int64_t* sum_depth,
                                void* stream) {
@@ -306,6 +374,21 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
                    d->K, md.A, md.K);
   const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
   SearchCtx c{*d, *in};
+  if (az_coop_applicable(d, lds)) {
+    const size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+    return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+      if constexpr (AMAX <= 8 && KMAX <= 8) {
+        if (int rc = az_set_lds((const void*)k_search_fused_coop<AMAX, KMAX>, lds2)) return rc;
+        k_search_fused_coop<AMAX, KMAX>
+            <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
+               (hipStream_t)stream>>>(c, *t, md, reinterpret_cast<unsigned long long*>(sum_depth));
+        AZ_LAUNCH_CHECK();
+        return AZ_OK;
+      } else {
+        return az_fail(AZ_ERR_UNSUPPORTED, "cooperative search dispatched beyond its bounds");
+      }
+    });
+  }
   return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
     if (int rc = az_set_lds((const void*)k_search_fused<AMAX, KMAX>, lds)) return rc;
     k_search_fused<AMAX, KMAX>

@@ -9,7 +9,10 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "az_host.h"
+#include "az_coop.h"
 
 // ---------------------------------------------------------------------------
 // tree init: one thread per (lane, node)
@@ -95,6 +98,67 @@ AZ_UNROLL_K
   az_add_depth(sum_depth, depth_sum);
 }
 
+// The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 16
+// threads per lane, cached selections and the path in LDS.
+template <int AMAX, int KMAX>
+__global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
+    SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const az_search_desc& d = c.d;
+  const int A = d.A, K = d.K, S = d.S;
+  const int tid = threadIdx.x, ln = tid >> 4, j = tid & (AZ_GROUP - 1);
+  const int b = blockIdx.x * AZ_WG_LANES + ln;
+  const bool active = b < d.B;
+  Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
+  CoopLds s(lds, ln, S);
+  if (j == 0) {
+    s.hdr[0] = -1;
+    if (active) az_coop_init<AMAX, KMAX>(c, l, s, b);
+  }
+  __syncthreads();
+  long long depth_sum = 0;
+  for (int sim = 0; sim < S; ++sim) {
+    // the recurrent_fn outputs of this (lane, simulation)
+    const size_t e = (size_t)(active ? b : 0) * S + sim;
+    float ev_logits[AMAX], ev_value[KMAX];
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) ev_logits[a] = inj.prior_logits[e * A + a];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k)
+      if (k < K) ev_value[k] = inj.value[e * K + k];
+    const float reward = inj.reward[e], discount = inj.discount[e];
+    if (j == 0 && active) depth_sum += az_coop_chase(s, sim, d.max_depth);
+    __syncthreads();
+    const int maxdep = az_coop_max_depth(lds, S);
+    const int dep = s.hdr[0], newn = s.hdr[1], parent = s.hdr[2], action = s.hdr[3];
+    for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
+      const int p = j + it * AZ_GROUP;
+      const bool mine = active && p <= dep;
+      CoopPos<AMAX, KMAX> P;
+      if (mine) az_coop_load<AMAX, KMAX>(l, s, p, dep, newn, P);
+      __syncthreads();
+      if (mine)
+        az_coop_apply<AMAX, KMAX>(c, l, s, b, p, dep, newn, parent, action, ev_logits, ev_value,
+                                  reward, discount, P);
+      __syncthreads();
+    }
+  }
+  az_add_depth(sum_depth, depth_sum);
+}
+
+// Whether the cooperative form applies (see az_coop.h) and fits in LDS next to
+// `extra_lds_bytes` of other use.  AZ_FORCE_LITERAL=1 in the environment selects the
+// literal kernels (used to cross-check the two forms).
+bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes) {
+  const char* force = getenv("AZ_FORCE_LITERAL");
+  if (force && force[0] == '1') return false;
+  if (!(d->variant == AZ_VARIANT_GUMBEL || d->noise_mode == AZ_NOISE_ZERO)) return false;
+  if (d->A > 8 || d->K > 8 || d->S + 1 > 65535) return false;
+  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + extra_lds_bytes;
+  return bytes <= 160 * 1024;
+}
+
 extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
                                   const az_search_inputs* in, const az_injected* inj,
                                   int64_t* sum_depth, void* stream) {
@@ -103,6 +167,23 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
   if (!inj || !inj->prior_logits || !inj->value || !inj->reward || !inj->discount)
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
+  if (az_coop_applicable(d, 0)) {
+    const size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+    return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
+      if constexpr (AMAX <= 8 && KMAX <= 8) {
+        if (lds > 48 * 1024)
+          AZ_HIP(hipFuncSetAttribute((const void*)k_search_coop_injected<AMAX, KMAX>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_search_coop_injected<AMAX, KMAX>
+            <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
+               (hipStream_t)stream>>>(c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
+        AZ_LAUNCH_CHECK();
+        return AZ_OK;
+      } else {
+        return az_fail(AZ_ERR_UNSUPPORTED, "cooperative search dispatched beyond its bounds");
+      }
+    });
+  }
   return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
     k_search_injected<AMAX, KMAX><<<dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
         c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
@@ -215,7 +296,7 @@ AZ_UNROLL_A
   for (int a = 1; a < AZ_TRIP_A; ++a)
     if (a < A && r.vis[a] > considered_visit) considered_visit = r.vis[a];
   float cq[AMAX], score[AMAX], rl[AMAX], x[AMAX], w[AMAX];
-  az_qtransform<AMAX, KMAX>(l, d, AZ_ROOT, r, cq);
+  az_qtransform<AMAX>(d, A, r, cq);
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) rl[a] = root_logits[(size_t)b * A + a];

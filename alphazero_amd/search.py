@@ -68,6 +68,20 @@ def _key_words(key):
     return (C.c_uint32 * 2)(*key)
 
 
+def _timed(stats, launch):
+    """Runs `launch`; when stats['record_events'] is set, brackets it with HIP events on the
+    launch stream and appends the (start, end) pair to stats['events']."""
+    if stats is not None and stats.get("record_events"):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        launch()
+        end.record()
+        stats.setdefault("events", []).append((start, end))
+    else:
+        launch()
+
+
 def build_desc(*, B, S, A, K, root_action_selection_fn, interior_action_selection_fn,
                max_depth, rng_key, tiebreak_noise):
     d = nat.SearchDesc()
@@ -164,8 +178,8 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
         tp.emb_state, tp.emb_time = nat.ptr(emb_state), nat.ptr(emb_time)
         nat.check(lib.az_tree_init(d, tp, nat.ptr(logits), nat.ptr(value2), nat.ptr(root_state),
                                    nat.ptr(root_time), stream))
-        nat.check(lib.az_search_fused(d, tp, inputs, recurrent_fn.model.native,
-                                      nat.ptr(sum_depth), stream))
+        _timed(stats, lambda: nat.check(lib.az_search_fused(
+            d, tp, inputs, recurrent_fn.model.native, nat.ptr(sum_depth), stream)))
         embeddings = {"state": emb_state, "time": emb_time}
     elif isinstance(recurrent_fn, InjectedRecurrentFn):
         inj = nat.Injected()
@@ -179,7 +193,8 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
         inj.reward, inj.discount = nat.ptr(ir), nat.ptr(idc)
         keep += [il, iv, ir, idc]
         nat.check(lib.az_tree_init(d, tp, nat.ptr(logits), nat.ptr(value2), None, None, stream))
-        nat.check(lib.az_search_injected(d, tp, inputs, inj, nat.ptr(sum_depth), stream))
+        _timed(stats, lambda: nat.check(lib.az_search_injected(
+            d, tp, inputs, inj, nat.ptr(sum_depth), stream)))
         embeddings = tree_map(lambda x: x.unsqueeze(1).expand(B, N, *x.shape[1:]), root.embedding)
     else:
         nat.check(lib.az_tree_init(d, tp, nat.ptr(logits), nat.ptr(value2), None, None, stream))
@@ -221,7 +236,6 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
 
     if stats is not None:
         stats["sum_depth"] = sum_depth
-        stats["keepalive"] = keep
     root_invalid = inv if inv is not None else torch.zeros_like(logits)
     return Tree(embeddings=embeddings, root_invalid_actions=root_invalid, extra_data=extra_data,
                 **arrays)

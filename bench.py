@@ -1,0 +1,220 @@
+"""Benchmark of the batched-MCTS self-play hot path on MI355X.
+
+One step = one actor step (alphazero.py:287-403) on B lanes per GPU: root forward,
+gumbel_muzero_policy with the fused env + MLP + tree search kernel (S simulations),
+greedy/sampled action post-processing and the auto-resetting real environment
+step.  metric = MCTS simulations/s (B*S node expansions per step), whole job.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Lanes are independent, so ranks shard them with no data-path collective (weak
+scaling: B lanes per GPU); the only collectives are the timing barrier and the
+max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_EXPANSION = {  # 2 * sum(in*out) over both MLPs (4x32 policy, 5x256 value)
+    "CartPole-v1": 533376, "Acrobot-v1": 534592, "MountainCar-v0": 532288}
+PEAK_F32_MFMA_TFLOPS = 157.3   # f32-input MFMA, MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
+    p.add_argument("--sims", type=int, default=64)
+    p.add_argument("--env", default="CartPole-v1")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-lanes", type=int, default=0, help="lanes of the CPU baseline sample")
+    return p.parse_args()
+
+
+def make_networks(env_id, seed, device):
+    import alphazero_amd as mctx
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    obs, act = mctx.envs.observation_size(env_id), mctx.envs.action_size(env_id)
+    pol = mctx.init_mlp((obs, 32, 32, 32, 32, act), generator=g, device=device)
+    val = mctx.init_mlp((obs, 256, 256, 256, 256, 256, 1), generator=g, device=device)
+    return pol, val
+
+
+class Actor:
+    """alphazero.py:287-403 actor_step with the search on the fused HIP path."""
+
+    def __init__(self, env_id, B, S, device, seed=0):
+        import alphazero_amd as mctx
+        self.mctx, self.B, self.S = mctx, B, S
+        self.env = mctx.envs.make(env_id, episode_length=500)
+        self.pol, self.val = make_networks(env_id, 1, device)
+        self.model = mctx.FusedModel(env_id, self.pol, self.val, gamma=0.99)
+        self.recurrent_fn = mctx.FusedRecurrentFn(self.model)
+        self.state = self.env.reset(seed, batch_size=B, device=device)
+        self.key = (0, seed)
+        self.qtransform = mctx.qtransform_completed_by_mix_value
+
+    def step(self, stats=None):
+        mctx = self.mctx
+        from alphazero_amd import prng
+        self.key, search_key = prng.split(self.key, 2)
+        logits, value = self.model.forward(self.state.obs)
+        root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=self.state.embedding)
+        out = mctx.gumbel_muzero_policy((), search_key, root, self.recurrent_fn, self.S,
+                                        max_num_considered_actions=16, qtransform=self.qtransform,
+                                        stats=stats)
+        action, search_value, log_prob = mctx.actor_post(out.search_tree, out.action_weights,
+                                                         out.action, logits, deterministic=False)
+        self.env.step_(self.state, action)
+        return out
+
+
+def tree_kernel_roofline(B, S, A, device, reps=5):
+    """The persistent tree kernel alone (injected evaluations) against the HBM roofline:
+    algorithmic bytes/sim = d*(24A+56) + 2E + 4A + 32 with E = 0 (no embedding), K = 1."""
+    import alphazero_amd as mctx
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    rf = mctx.InjectedRecurrentFn(
+        torch.randn((B, S, A), generator=g, device=device),
+        torch.rand((B, S, 1), generator=g, device=device) * 2 - 1,
+        torch.ones((B, S), device=device), torch.full((B, S), 0.99, device=device))
+    root = mctx.RootFnOutput(prior_logits=torch.randn((B, A), generator=g, device=device),
+                             value=torch.rand((B, 1), generator=g, device=device) * 2 - 1,
+                             embedding=None)
+    times, sum_depth = [], 0
+    for i in range(reps + 1):
+        stats = {"record_events": True}
+        mctx.gumbel_muzero_policy((), i, root, rf, S, stats=stats)
+        torch.cuda.synchronize()
+        if i:
+            times.append(stats["events"][0][0].elapsed_time(stats["events"][0][1]) * 1e-3)
+            sum_depth = int(stats["sum_depth"].item())
+    t = float(np.mean(times))
+    alg_bytes = sum_depth * (24 * A + 56) + B * S * (4 * A + 32)
+    achieved = alg_bytes / t / 1e9
+    return {"kernel": "k_search_injected", "bound": "hbm", "achieved": round(achieved, 2),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
+            "traffic": None, "ms_per_launch": round(t * 1e3, 4),
+            "mean_depth": round(sum_depth / (B * S), 3),
+            "sims_per_s": round(B * S / t, 1)}
+
+
+def cpu_baseline(env_id, S, lanes, threads):
+    """The plain-C restatement (oracle/) of the same fused search, on `threads` host
+    threads over `lanes` lanes of the same synthetic workload."""
+    from oracle import runners
+    per = max(1, lanes // threads)
+    cases = [runners.synthetic_case("gumbel", B=per, S=S, K=1, seed=100 + i, env_id=env_id)
+             for i in range(threads)]
+    t0 = time.perf_counter()
+    workers = [threading.Thread(target=runners.run_policy_c, args=(c,)) for c in cases]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    dt = time.perf_counter() - t0
+    n = per * threads
+    return {"value": round(n * S / dt, 1), "unit": "simulations/s", "cores": threads, "kind": "port",
+            "sample": f"{n} lanes x {S} simulations of the same fused CartPole Gumbel search "
+                      f"(plain-C checker, {threads} threads), {dt:.1f} s",
+            "env_steps_per_s": round(n / dt, 2)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run "
+                             "(--nproc-per-node must equal --gpus)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B, S = args.batch, args.sims
+    actor = Actor(args.env, B, S, device, seed=1000 + rank)
+    for _ in range(args.warmup):
+        actor.step()
+    barrier()
+    stats_list = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = {"record_events": True}
+        actor.step(stats)
+        stats_list.append(stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the fused persistent search, timed with HIP events on its stream
+    ktimes = [s["events"][0][0].elapsed_time(s["events"][0][1]) * 1e-3 for s in stats_list]
+    kt = float(np.mean(ktimes))
+    flop = FLOP_PER_EXPANSION[args.env] * B * S
+    achieved = flop / kt / 1e12
+    sum_depth = int(stats_list[-1]["sum_depth"].item())
+
+    if rank == 0:
+        line = {
+            "metric": "MCTS simulations/s", "value": round(world * B * S * args.steps / elapsed, 1),
+            "unit": "simulations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.env} gumbel_muzero_policy actor step, fused env+MLP+tree "
+                                   f"search, batch {B} lanes/GPU x {S} simulations, policy MLP 4x32, "
+                                   f"value MLP 5x256, random-init weights",
+                       "lanes_per_gpu": B, "num_simulations": S, "max_num_considered_actions": 16,
+                       "parallelism": f"lanes sharded over {world} GPU(s), no data-path collective"},
+            "env_steps_per_s": round(world * B * args.steps / elapsed, 1),
+            "roofline": {"kernel": "k_search_fused", "bound": "mfma", "achieved": round(achieved, 3),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+                         "ms_per_launch": round(kt * 1e3, 4),
+                         "mean_depth": round(sum_depth / (B * S), 3)},
+        }
+        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_search_fused_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1:
+            line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
+            if not args.no_cpu_baseline:
+                threads = min(16, os.cpu_count() or 1)
+                lanes = args.cpu_lanes or 512 * threads  # ~10-15 s of wall time
+                line["cpu_baseline"] = cpu_baseline(args.env, S, lanes, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

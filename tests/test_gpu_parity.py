@@ -211,6 +211,58 @@ def test_fused_equals_callback_path(hip):
     hip.assert_same(a, b)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(variant="gumbel", B=40, S=64, A=2, K=1),
+    dict(variant="gumbel", B=20, S=48, A=3, K=4, with_invalid=True),
+    dict(variant="gumbel", B=20, S=40, A=2, K=1, max_depth=5),
+    dict(variant="gumbel", B=20, S=40, A=2, K=1, max_depth=1),
+    dict(variant="gumbel", B=10, S=40, A=8, K=8),
+], ids=_ids)
+def test_literal_and_cooperative_tree_kernels_agree(hip, kw, monkeypatch):
+    """The literal one-thread-per-lane kernel and the cooperative 16-threads-per-lane kernel
+    (cached selections in LDS) build bit-identical trees, and both equal the CPU checker."""
+    case = _case(kw, seed=51)
+    coop = hip.run_policy_hip(case, "persistent")
+    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
+    literal = hip.run_policy_hip(case, "persistent")
+    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    hip.assert_same(coop, literal)
+    hip.assert_same(coop, runners.run_policy_c(case))
+    assert coop["sum_depth"] > case["B"] * case["S"] or case.get("max_depth") == 1
+
+
+def test_cooperative_kernel_with_zero_noise_puct(hip, oracle):
+    """PUCT selection with the tie-break noise disabled also runs in the cooperative form."""
+    import alphazero_amd as mctx
+    case = runners.synthetic_case("muzero", B=24, S=32, A=3, K=2, seed=53)
+    case["tie_noise"] = None
+    ref = runners.run_policy_c(case)
+    ev = {k: hip.dev(x) for k, x in case["evals"].items()}
+    rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"], ev["reward"], ev["discount"])
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"]),
+                             embedding=None)
+    out = mctx.muzero_policy((), 0, root, rf, 32, dirichlet_noise=hip.dev(case["dirichlet"]),
+                             tiebreak_noise="zero", action_gumbel=hip.dev(case["action_gumbel"]))
+    t = out.search_tree
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS:
+        assert np.array_equal(getattr(t, f).cpu().numpy(), ref[f]), f
+    assert np.array_equal(out.action.cpu().numpy(), ref["action"])
+
+
+def test_literal_and_cooperative_fused_kernels_agree(hip, monkeypatch):
+    case = runners.synthetic_case("gumbel", B=40, S=48, K=1, seed=55, env_id="CartPole-v1",
+                                  policy_hidden=(32, 32), value_hidden=(64, 64))
+    coop = hip.run_policy_hip(case, "persistent")
+    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
+    literal = hip.run_policy_hip(case, "persistent")
+    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    hip.assert_same(coop, literal)
+    assert np.array_equal(coop["emb_state"], literal["emb_state"])
+    ref = runners.run_policy_c(case)
+    hip.assert_same(coop, ref)
+    assert np.array_equal(coop["emb_state"], ref["emb_state"])
+
+
 # ---------------------------------------------------------------- full size, properties
 def check_invariants(out, S):
     nv, cv, ci = out["node_visits"], out["children_visits"], out["children_index"]
