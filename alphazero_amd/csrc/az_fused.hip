@@ -103,46 +103,26 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   md->K = m->num_atoms;
   int64_t off = az_mlp_layout(pp.n_layers, pp.sizes, 0, &md->pol);
   az_mlp_layout(vp.n_layers, vp.sizes, off, &md->val);
-  int mk = 16;
-  for (int i = 0; i < md->pol.n_layers; ++i) mk = md->pol.np[i] > mk ? md->pol.np[i] : mk;
-  for (int i = 0; i < md->val.n_layers; ++i) mk = md->val.np[i] > mk ? md->val.np[i] : mk;
-  md->max_kp = mk;
+  int pk = 64, vk = 64;
+  for (int i = 0; i < md->pol.n_layers; ++i) pk = md->pol.np[i] > pk ? md->pol.np[i] : pk;
+  for (int i = 0; i < md->val.n_layers; ++i) vk = md->val.np[i] > vk ? md->val.np[i] : vk;
+  md->pol_kp = pk;
+  md->val_kp = vk;
   md->packed = m->packed;
   md->mean = m->norm_mean;
   md->std = m->norm_std;
-  if ((size_t)az_mlp_lds_floats(mk) * 4 > 160 * 1024)
-    return az_fail(AZ_ERR_UNSUPPORTED, "layer width %d needs more than 160 KiB of LDS", mk);
+  if ((size_t)az_mlp_lds_floats(pk, vk) * 4 > 160 * 1024)
+    return az_fail(AZ_ERR_UNSUPPORTED, "layer widths %d / %d need more than 160 KiB of LDS", pk, vk);
   return AZ_OK;
 }
 
 #define AZ_MLP_WAVES 8
 
-struct MlpLds {
-  float *in0, *bufa, *bufb, *logits, *value;
-  int stride;
-  AZ_DEV MlpLds(float* base, int max_kp) {
-    stride = az_act_stride(max_kp);
-    in0 = base;
-    bufa = in0 + 16 * stride;
-    bufb = bufa + 16 * stride;
-    logits = bufb + 16 * stride;
-    value = logits + 16 * AZ_MAX_ACTIONS;
-  }
-};
-
 // running_statistics.py:183-199 on one observation row, written in the permuted
-// activation layout of the first dense layer (Kp = 16).
+// activation layout of the first dense layer (Kp = 64).
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
   for (int i = 0; i < md.obs_dim; ++i)
-    s.in0[row * s.stride + az_act_index(i, 16)] = (obs[i] - md.mean[i]) / md.std[i];
-}
-
-// both networks on the 16 rows staged in s.in0 -> s.logits / s.value
-AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane) {
-  az_mlp_tile16<AZ_MLP_WAVES>(md.pol, md.packed, s.in0, s.bufa, s.bufb, s.logits, AZ_MAX_ACTIONS,
-                              s.stride, wave, lane);
-  az_mlp_tile16<AZ_MLP_WAVES>(md.val, md.packed, s.in0, s.bufa, s.bufb, s.value, AZ_MAX_ATOMS,
-                              s.stride, wave, lane);
+    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, 64)] = (obs[i] - md.mean[i]) / md.std[i];
 }
 
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
@@ -150,14 +130,14 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
                                                                float* __restrict__ logits,
                                                                float* __restrict__ value) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  MlpLds s(lds, md.max_kp);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  MlpLds s(lds, md.pol_kp, md.val_kp);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
-  az_forward_tile(md, s, wave, lane);
+  az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -175,7 +155,7 @@ extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float*
   ModelDev md;
   if (int rc = az_model_dev(m, &md)) return rc;
   if (B < 1 || !obs || !logits || !value) return az_fail(AZ_ERR_INVALID, "bad forward arguments");
-  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   if (int rc = az_set_lds((const void*)k_forward, lds)) return rc;
   k_forward<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
       md, B, obs, logits, value);
@@ -196,9 +176,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
     const int32_t* __restrict__ action, float* __restrict__ reward, float* __restrict__ discount,
     float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  MlpLds s(lds, md.max_kp);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  MlpLds s(lds, md.pol_kp, md.val_kp);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) {
@@ -215,7 +195,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
     az_store_obs(md, s, tid, o.obs);
   }
   __syncthreads();
-  az_forward_tile(md, s, wave, lane);
+  az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -229,7 +209,7 @@ extern "C" int az_recurrent_step(const az_model* m, int32_t B, float* state, int
   if (int rc = az_model_dev(m, &md)) return rc;
   if (B < 1 || !state || !time || !action || !reward || !discount || !logits || !value)
     return az_fail(AZ_ERR_INVALID, "bad recurrent_step arguments");
-  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   if (int rc = az_set_lds((const void*)k_recurrent_step, lds)) return rc;
   k_recurrent_step<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
       md, B, state, time, action, reward, discount, logits, value);
@@ -247,12 +227,12 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
                                                                     unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
-  MlpLds s(lds, md.max_kp);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MlpLds s(lds, md.pol_kp, md.val_kp);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int b = blockIdx.x * 16 + tid;
   const bool active = tid < 16 && b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, d.S + 1, d.A, d.K);
-  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
   __syncthreads();
   const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   uint32_t r0 = d.key[0], r1 = d.key[1];
@@ -280,7 +260,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
       az_store_obs(md, s, tid, o.obs);
     }
     __syncthreads();
-    az_forward_tile(md, s, wave, lane);
+    az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
     if (active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) l.es[(size_t)node * 4 + i] = st.s[i];
@@ -302,9 +282,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
-  MlpLds s(lds, md.max_kp);
-  float* tree_lds = lds + az_mlp_lds_floats(md.max_kp);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MlpLds s(lds, md.pol_kp, md.val_kp);
+  float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool tree_thread = tid < AZ_TREE_THREADS;
   const int ln = (tid >> 4) & (AZ_WG_LANES - 1), j = tid & (AZ_GROUP - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
@@ -312,7 +292,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
   const bool leader = active && j == 0;
   Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
   CoopLds cs(tree_lds, ln, S);
-  for (int i = tid; i < 16 * s.stride; i += blockDim.x) s.in0[i] = 0.0f;
+  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
   if (tree_thread && j == 0) {
     cs.hdr[0] = -1;
     if (active) az_coop_init<AMAX, KMAX>(c, l, cs, b);
@@ -335,7 +315,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
       az_store_obs(md, s, ln, o.obs);
     }
     __syncthreads();
-    az_forward_tile(md, s, wave, lane);
+    az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
     const int maxdep = az_coop_max_depth(tree_lds, S);
     const int dep = cs.hdr[0], newn = cs.hdr[1], parent = cs.hdr[2], action = cs.hdr[3];
     const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
@@ -372,7 +352,7 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   if (d->A != md.A || d->K != md.K)
     return az_fail(AZ_ERR_INVALID, "search A=%d K=%d do not match the model's A=%d K=%d", d->A,
                    d->K, md.A, md.K);
-  const size_t lds = (size_t)az_mlp_lds_floats(md.max_kp) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, lds)) {
     const size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
@@ -399,3 +379,12 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   });
 }
 
+
+#ifdef AZ_STAMP
+// Diagnostic build only: copies the cycle stamps of the last forward to the host.
+extern "C" int az_debug_read_stamps(long long* host_out) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_stamps), sizeof(long long) * 8 * 64));
+  return AZ_OK;
+}
+#endif
