@@ -137,9 +137,8 @@ def cpu_baseline(env_id, S, lanes, threads):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from alphazero_amd import parallel
+    rank, world, local = parallel.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run "
@@ -156,8 +155,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    B, S = args.batch, args.sims
-    actor = Actor(args.env, B, S, device, seed=1000 + rank)
+    S = args.sims
+    shard = parallel.shard_lanes(args.batch, rank, world, key=1000, weak=True)
+    B = shard.lanes
+    actor = Actor(args.env, B, S, device, seed=shard.key[1])
     for _ in range(args.warmup):
         actor.step()
     barrier()
@@ -168,11 +169,8 @@ def main():
         actor.step(stats)
         stats_list.append(stats)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    total_sims = parallel.sum_over_ranks(B * S * args.steps, device=device)
 
     # dominant kernel: the fused persistent search, timed with HIP events on its stream
     ktimes = [s["events"][0][0].elapsed_time(s["events"][0][1]) * 1e-3 for s in stats_list]
@@ -183,7 +181,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "MCTS simulations/s", "value": round(world * B * S * args.steps / elapsed, 1),
+            "metric": "MCTS simulations/s", "value": round(total_sims / elapsed, 1),
             "unit": "simulations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -192,7 +190,7 @@ def main():
                                    f"value MLP 5x256, random-init weights",
                        "lanes_per_gpu": B, "num_simulations": S, "max_num_considered_actions": 16,
                        "parallelism": f"lanes sharded over {world} GPU(s), no data-path collective"},
-            "env_steps_per_s": round(world * B * args.steps / elapsed, 1),
+            "env_steps_per_s": round(total_sims / S / elapsed, 1),
             "roofline": {"kernel": "k_search_fused", "bound": "mfma", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,

@@ -1,0 +1,48 @@
+"""Condenses rocprofv3 output directories into the small files committed under profiles/.
+
+usage: summarize_profile.py <round-tag> <stats_dir> [<fetch_pmc_dir> <write_pmc_dir>]
+"""
+import csv, glob, json, os, sys, collections
+
+tag, stats_dir = sys.argv[1], sys.argv[2]
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(root, exist_ok=True)
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+ks = find(stats_dir, "kernel_stats.csv")
+rows = list(csv.DictReader(open(ks)))
+with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        name = r["Name"]
+        name = name if len(name) < 120 else name[:117] + "..."
+        w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+print(open(os.path.join(root, f"{tag}_kernel_stats.csv")).read()[:1500])
+
+if len(sys.argv) >= 5:
+    out = {}
+    for label, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+        cc = find(d, "counter_collection.csv")
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(cc)):
+            if r["Counter_Name"] == label:
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            out.setdefault(k, {})[label + "_KB_mean"] = sum(v) / len(v)
+            out[k]["launches"] = len(v)
+    res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per launch, KB. "
+                   "gfx950 correction: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads, "
+                   "so read bytes = 2 * FETCH_SIZE * 1024; other access widths are uncalibrated.",
+           "kernels": out}
+    for k, v in out.items():
+        if "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
+            v["hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE_KB_mean"] * 1024 + v["WRITE_SIZE_KB_mean"] * 1024
+    for k, v in out.items():
+        if k.startswith("void k_search_fused") or k.startswith("k_search_fused"):
+            res["k_search_fused_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
+    json.dump(res, open(os.path.join(root, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1)[:3000])
