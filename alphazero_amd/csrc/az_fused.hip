@@ -116,13 +116,12 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   return AZ_OK;
 }
 
-#define AZ_MLP_WAVES 8
-
 // running_statistics.py:183-199 on one observation row, written in the permuted
-// activation layout of the first dense layer (Kp = 64).
+// activation layout of the first dense layer (both networks read the same rows).
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
+  const int kp = md.val.kp[0];
   for (int i = 0; i < md.obs_dim; ++i)
-    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, 64)] = (obs[i] - md.mean[i]) / md.std[i];
+    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = (obs[i] - md.mean[i]) / md.std[i];
 }
 
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
@@ -137,7 +136,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
-  az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
+  MlpRegs regs;
+  az_forward_prime<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+  az_forward_tile<AZ_MLP_WAVES, false, false>(md, s, wave, lane, regs);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -195,7 +196,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
     az_store_obs(md, s, tid, o.obs);
   }
   __syncthreads();
-  az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
+  MlpRegs regs;
+  az_forward_prime<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+  az_forward_tile<AZ_MLP_WAVES, false, false>(md, s, wave, lane, regs);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -233,7 +236,10 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   const bool active = tid < 16 && b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, d.S + 1, d.A, d.K);
   for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
+  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
+  MlpRegs regs;
+  az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
   const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   uint32_t r0 = d.key[0], r1 = d.key[1];
   long long depth_sum = 0;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
       az_store_obs(md, s, tid, o.obs);
     }
     __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
+    az_forward_tile<AZ_MLP_WAVES, true, true>(md, s, wave, lane, regs);
     if (active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) l.es[(size_t)node * 4 + i] = st.s[i];
@@ -297,7 +303,10 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
     cs.hdr[0] = -1;
     if (active) az_coop_init<AMAX, KMAX>(c, l, cs, b);
   }
+  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
+  MlpRegs regs;
+  az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
   long long depth_sum = 0;
   for (int sim = 0; sim < S; ++sim) {
     EnvState st;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
       az_store_obs(md, s, ln, o.obs);
     }
     __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES>(md, s, wave, lane);
+    az_forward_tile<AZ_MLP_WAVES, true, true>(md, s, wave, lane, regs);
     const int maxdep = az_coop_max_depth(tree_lds, S);
     const int dep = cs.hdr[0], newn = cs.hdr[1], parent = cs.hdr[2], action = cs.hdr[3];
     const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);

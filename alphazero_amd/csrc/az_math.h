@@ -65,11 +65,16 @@ AZ_HD float az_pow2i(int k) { return az_u2f((uint32_t)(k + 127) << 23); }
  * the linear terms, and a two-step power-of-two scaling so that results in the
  * subnormal range are rounded once. */
 AZ_HD float az_expf(float x) {
-  if (x != x) return x;
-  if (x > 88.72283935546875f) return AZ_INF;
-  if (x < -103.97208404541015625f) return 0.0f;
-  float kf = (x * 1.44269502162933349609375f + 12582912.0f) - 12582912.0f;
-  float r = az_fmaf(kf, -0.693359375f, x);
+  /* Branch-free on purpose (selects, no early returns): on the GPU this runs in
+   * the epilogue of every dense layer, where divergent branches cost more than
+   * the arithmetic.  Out-of-range and NaN inputs are computed on a stand-in and
+   * replaced at the end. */
+  const int is_nan = x != x;
+  const int over = x > 88.72283935546875f;
+  const int under = x < -103.97208404541015625f;
+  const float xs = (is_nan | over | under) ? 0.0f : x;
+  float kf = (xs * 1.44269502162933349609375f + 12582912.0f) - 12582912.0f;
+  float r = az_fmaf(kf, -0.693359375f, xs);
   r = az_fmaf(kf, 2.12194440e-4f, r);
   float p = 1.9875691500e-4f;
   p = az_fmaf(p, r, 1.3981999507e-3f);
@@ -82,7 +87,10 @@ AZ_HD float az_expf(float x) {
   int k = (int)kf;
   int k1 = k >> 1;
   int k2 = k - k1;
-  return (p * az_pow2i(k1)) * az_pow2i(k2);
+  float y = (p * az_pow2i(k1)) * az_pow2i(k2);
+  y = under ? 0.0f : y;
+  y = over ? AZ_INF : y;
+  return is_nan ? x : y;
 }
 
 /* log(x): frexp by bit manipulation (subnormals pre-scaled by 2^23), the

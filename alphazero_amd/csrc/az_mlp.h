@@ -7,10 +7,8 @@
 // search stays bit-identical to the host evaluation while the contraction runs
 // on the matrix pipe instead of the vector ALU.
 //
-// Data layout.  A dense layer in -> out is padded to Kp = ceil64(in) and Np = ceil64(out)
-// (Np = ceil16(out) for a network's last layer), so that the k-loop always runs whole
-// chunks of four 16-row k-blocks; the padding is zeros, which leave an accumulator
-// that started at +0 unchanged.
+// Data layout.  A dense layer in -> out is padded to Kp = ceil16(in) and Np = ceil16(out);
+// the padding is zeros, which leave an accumulator that started at +0 unchanged.
 //  * Packed weights: for output tile t (16 columns) and k-block kb (16 rows) one
 //    float4 per lane,  Wp[t][kb][lane][q] = W[16*kb + 4*q + (lane>>4)][16*t + (lane&15)],
 //    i.e. the B operand of four consecutive MFMA k-steps; a wave reads 1 KiB
@@ -21,19 +19,33 @@
 //
 // Schedule.  Layer i of the policy network and layer i of the value network form
 // phase i (one workgroup barrier per phase).  A phase's work items are pairs of
-// output tiles; wave w takes items w, w + NWAVES, ...  With M = 16 every weight is
-// used for only 16 multiply-adds, so the kernel is bound by streaming weights from
-// L2, not by the matrix pipe alone: a wave holds the 16 k-blocks of its current unit
-// in 128 VGPRs and refills each register slot, right after the MFMAs that consumed
-// it, with the same k-block of its NEXT unit -- which may belong to the next phase,
-// since weights do not depend on activations -- so up to 32 KiB per wave stay in
-// flight behind the MFMAs, the epilogue and the barrier.
+// output tiles of the value layer; wave w takes items w, w + NWAVES, ...  A tile of a
+// narrow policy layer (at most AZ_RIDER_SLOTS k-blocks) rides along on a value item
+// as a third accumulator, so the small network adds a few MFMAs to a wave instead
+// of a unit of its own on the phase's critical path; policy tiles that do not fit
+// that way form pairs of their own after the value items.  With M = 16 every weight
+// is used for only 16 multiply-adds, so a wave holds the 16 k-blocks of its current
+// unit in 128 VGPRs and refills each register slot, right after the MFMAs that
+// consumed it, with the same k-block of its NEXT unit -- which may belong to the next
+// phase or, in the persistent search, to the next simulation, since weights do not
+// depend on activations -- so up to 32 KiB per wave stay in flight behind the MFMAs,
+// the epilogue, the barrier and the tree phase.  The unit descriptors of a persistent
+// kernel are computed once into an LDS table.
 #ifndef AZ_MLP_H_
 #define AZ_MLP_H_
 
 #include "az_device.h"
 
 typedef __attribute__((ext_vector_type(4))) float az_f32x4;
+
+// Loads through pointers that are known to address global memory.  Pointers that
+// went through the LDS descriptor table are generic to the compiler, and a generic
+// (flat) load counts against the LDS counter as well, which would make every wait
+// for an A operand wait for the weight prefetch too.
+AZ_DEV az_f32x4 az_ldg4(const az_f32x4* p) {
+  return *(const __attribute__((address_space(1))) az_f32x4*)p;
+}
+AZ_DEV float az_ldg(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
 
 
 struct MlpLayout {
@@ -55,8 +67,12 @@ struct ModelDev {
 };
 
 __host__ __device__ inline int az_ceil16(int x) { return (x + 15) & ~15; }
-__host__ __device__ inline int az_ceil64(int x) { return (x + 63) & ~63; }
-#define AZ_IN0_STRIDE 68  // row stride of the first layer's input buffer (Kp = 64, + 4)
+#define AZ_IN0_STRIDE 68  // row stride of the first layer's input buffer (Kp <= 64, + 4)
+#define AZ_SLOTS 16       // k-blocks of one unit held in registers per tile
+#define AZ_RIDER_SLOTS 4  // k-blocks of a rider tile
+#define AZ_MLP_WAVES 8    // waves of a workgroup that run the networks
+#define AZ_TABLE_UNITS 16 // unit descriptors per wave in the LDS table
+#define AZ_UNIT_WORDS 36  // 32-bit words of one descriptor (sizeof(MlpUnit) / 4)
 
 // Fills `L` from the layer sizes; returns the offset just past this network.
 inline int64_t az_mlp_layout(int n_layers, const int32_t* sizes, int64_t base, MlpLayout* L) {
@@ -65,8 +81,8 @@ inline int64_t az_mlp_layout(int n_layers, const int32_t* sizes, int64_t base, M
   for (int i = 0; i < n_layers; ++i) {
     L->kin[i] = sizes[i];
     L->nout[i] = sizes[i + 1];
-    L->kp[i] = az_ceil64(sizes[i]);
-    L->np[i] = i == n_layers - 1 ? az_ceil16(sizes[i + 1]) : az_ceil64(sizes[i + 1]);
+    L->kp[i] = az_ceil16(sizes[i]);
+    L->np[i] = az_ceil16(sizes[i + 1]);
     L->w_off[i] = off;
     off += (int64_t)L->kp[i] * L->np[i];
     L->b_off[i] = off;
@@ -83,16 +99,21 @@ __host__ __device__ inline int az_act_stride(int kp) { return kp + 4; }
 AZ_DEV int az_act_index(int k, int kp) { return (k & 3) * (kp >> 2) + (k >> 2); }
 
 // LDS floats of the network scratch: in0 [16][AZ_IN0_STRIDE], two ping-pong activation buffers
-// per network, logits [16][AZ_MAX_ACTIONS], values [16][AZ_MAX_ATOMS].
+// per network, logits [16][AZ_MAX_ACTIONS], values [16][AZ_MAX_ATOMS], the unit table
+// [AZ_MLP_WAVES][AZ_TABLE_UNITS][AZ_UNIT_WORDS] and its per-wave counts.
 __host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp) {
   return 16 * AZ_IN0_STRIDE + 2 * 16 * az_act_stride(pol_kp) + 2 * 16 * az_act_stride(val_kp) +
-         16 * AZ_MAX_ACTIONS + 16 * AZ_MAX_ATOMS;
+         16 * AZ_MAX_ACTIONS + 16 * AZ_MAX_ATOMS +
+         AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS + 16;
 }
 
 struct MlpLds {
-  float *in0, *pa, *pb, *va, *vb, *logits, *value;
+  float *base, *in0, *pa, *pb, *va, *vb, *logits, *value;
+  uint32_t* tab;   // unit table; 16-byte aligned because every region is a multiple of 4 floats
+  int32_t* tab_n;  // units of each wave in the table, or -1 when they do not fit
   int pstride, vstride;
-  AZ_DEV MlpLds(float* base, int pol_kp, int val_kp) {
+  AZ_DEV MlpLds(float* base_, int pol_kp, int val_kp) {
+    base = base_;
     pstride = az_act_stride(pol_kp);
     vstride = az_act_stride(val_kp);
     in0 = base;
@@ -102,95 +123,182 @@ struct MlpLds {
     vb = va + 16 * vstride;
     logits = vb + 16 * vstride;
     value = logits + 16 * AZ_MAX_ACTIONS;
+    tab = reinterpret_cast<uint32_t*>(value + 16 * AZ_MAX_ATOMS);
+    tab_n = reinterpret_cast<int32_t*>(tab + AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS);
   }
 };
 
-// One unit of work: a pair of output tiles of one layer of one network, restricted to
-// one round of AZ_SLOTS k-blocks (layers wider than 16*AZ_SLOTS inputs take several
-// rounds; the accumulators carry over).
-#define AZ_SLOTS 16
-
-struct MlpUnit {
-  const az_f32x4* w0;  // packed weights of tile t0 for this round (+ lane), kb stride 64
-  const az_f32x4* w1;  // tile t0 + 1, or w0 again when the pair is incomplete
-  const float* bias;
-  const float* ap;     // this lane's A operands for the round (LDS)
-  float* out_act;      // next layer's activations (LDS), or null for the last layer
-  float* out_plain;    // [16][out_stride] for the last layer
-  int out_stride, out_np, nout, nkb, t0;
-  int phase, idx, round;
-  bool two, first, last, valid;
+// Where the results of one 16-column output tile go.
+struct MlpTile {
+  const float* bias;  // at the tile's first column
+  int out_off;        // float offset from MlpLds::base of the output buffer
+  int out_stride, out_np, nout, n0;
+  int act;            // 1: swish into the next layer's permuted activations; 0: plain [16][out_stride]
 };
 
-AZ_DEV int az_phase_items(const ModelDev& md, int phase, int& n_val) {
-  n_val = phase < md.val.n_layers ? ((md.val.np[phase] >> 4) + 1) >> 1 : 0;
-  const int n_pol = phase < md.pol.n_layers ? ((md.pol.np[phase] >> 4) + 1) >> 1 : 0;
-  return n_val + n_pol;
+enum { AZ_U_VALID = 1, AZ_U_TWO = 2, AZ_U_FIRST = 4, AZ_U_LAST = 8, AZ_U_RIDER = 16 };
+
+// One unit of work: a pair of output tiles of one layer, restricted to one round of
+// AZ_SLOTS k-blocks (layers wider than 16*AZ_SLOTS inputs take several rounds; the
+// accumulators carry over), plus an optional rider tile of the other network.
+// Plain data without lane-dependent parts, so that it can live in the LDS table.
+struct MlpUnit {
+  const az_f32x4 *w0, *w1, *w2;  // packed weights of tiles t0, t0 + 1 and the rider (kb stride 64)
+  MlpTile o0, o2;                // outputs of the pair (second tile: columns n0 + 16 ..) and the rider
+  int ap_off, in_stride, kpq, nkb;      // A operands of the pair: LDS offset, row stride, Kp / 4
+  int ap2_off, in_stride2, kpq2, nkb2;  // A operands of the rider
+  int phase, idx, round, flags;
+  int pad[2];
+};
+static_assert(sizeof(MlpUnit) == AZ_UNIT_WORDS * 4, "AZ_UNIT_WORDS must match MlpUnit");
+
+struct PhaseShape {
+  int n_val;     // pairs of value tiles
+  int n_riders;  // policy tiles riding on value items 0 .. n_riders - 1
+  int n_pol;     // pairs of the remaining policy tiles
+  int n;         // items of the phase
+};
+
+AZ_DEV PhaseShape az_phase_shape(const ModelDev& md, int phase) {
+  PhaseShape p;
+  const int tv = phase < md.val.n_layers ? md.val.np[phase] >> 4 : 0;
+  const int tp = phase < md.pol.n_layers ? md.pol.np[phase] >> 4 : 0;
+  p.n_val = (tv + 1) >> 1;
+  const bool ride = p.n_val > 0 && tp > 0 && (md.pol.kp[phase] >> 4) <= AZ_RIDER_SLOTS;
+  p.n_riders = ride ? (tp < p.n_val ? tp : p.n_val) : 0;
+  p.n_pol = (tp - p.n_riders + 1) >> 1;
+  p.n = p.n_val + p.n_pol;
+  return p;
 }
 
-AZ_DEV MlpUnit az_mlp_unit(const ModelDev& md, const MlpLds& s, int phase, int idx, int round,
-                           int lane) {
+AZ_DEV void az_mlp_tile_in(const ModelDev& md, const MlpLds& s, bool is_val, int phase, int kb_base,
+                           int& ap_off, int& in_stride, int& kpq) {
+  const MlpLayout& L = is_val ? md.val : md.pol;
+  const float* a = is_val ? s.va : s.pa;
+  const float* b = is_val ? s.vb : s.pb;
+  // phase 0 reads in0; phase i > 0 reads the buffer phase i-1 wrote
+  const float* in = phase == 0 ? s.in0 : ((phase & 1) ? a : b);
+  in_stride = phase == 0 ? AZ_IN0_STRIDE : (is_val ? s.vstride : s.pstride);
+  kpq = L.kp[phase] >> 2;
+  ap_off = (int)(in - s.base) + kb_base * 4;
+}
+
+AZ_DEV void az_mlp_tile_out(const ModelDev& md, const MlpLds& s, bool is_val, int phase, int tile,
+                            MlpTile& o) {
+  const MlpLayout& L = is_val ? md.val : md.pol;
+  const bool last_layer = phase == L.n_layers - 1;
+  float* a = is_val ? s.va : s.pa;
+  float* b = is_val ? s.vb : s.pb;
+  float* out = last_layer ? (is_val ? s.value : s.logits) : ((phase & 1) ? b : a);
+  o.bias = md.packed + L.b_off[phase] + tile * 16;
+  o.out_off = (int)(out - s.base);
+  o.out_stride = last_layer ? (is_val ? AZ_MAX_ATOMS : AZ_MAX_ACTIONS) : (is_val ? s.vstride : s.pstride);
+  o.out_np = L.np[phase];
+  o.nout = L.nout[phase];
+  o.n0 = tile * 16;
+  o.act = last_layer ? 0 : 1;
+}
+
+AZ_DEV MlpUnit az_mlp_unit(const ModelDev& md, const MlpLds& s, int phase, int idx, int round) {
   MlpUnit u;
   u.phase = phase;
   u.idx = idx;
   u.round = round;
-  u.valid = true;
-  int n_val;
-  az_phase_items(md, phase, n_val);
-  const bool is_val = idx < n_val;
+  u.pad[0] = u.pad[1] = 0;
+  const PhaseShape ps = az_phase_shape(md, phase);
+  const bool is_val = idx < ps.n_val;
   const MlpLayout& L = is_val ? md.val : md.pol;
-  const int pair = is_val ? idx : idx - n_val;
-  const int kp = L.kp[phase], np = L.np[phase];
-  const int nkb_total = kp >> 4;
+  const int t0 = is_val ? idx * 2 : ps.n_riders + (idx - ps.n_val) * 2;
+  const int nkb_total = L.kp[phase] >> 4;
   const int kb_base = round * AZ_SLOTS;
   u.nkb = nkb_total - kb_base < AZ_SLOTS ? nkb_total - kb_base : AZ_SLOTS;
-  u.first = round == 0;
-  u.last = kb_base + AZ_SLOTS >= nkb_total;
-  u.t0 = pair * 2;
-  u.two = u.t0 + 1 < (np >> 4);
+  const bool two = t0 + 1 < (L.np[phase] >> 4);
+  const bool rider = is_val && idx < ps.n_riders && round == 0;
+  u.flags = AZ_U_VALID | (two ? AZ_U_TWO : 0) | (round == 0 ? AZ_U_FIRST : 0) |
+            (kb_base + AZ_SLOTS >= nkb_total ? AZ_U_LAST : 0) | (rider ? AZ_U_RIDER : 0);
   const az_f32x4* wbase = reinterpret_cast<const az_f32x4*>(md.packed + L.w_off[phase]);
-  u.w0 = wbase + ((size_t)u.t0 * nkb_total + kb_base) * 64 + lane;
-  u.w1 = u.two ? u.w0 + (size_t)nkb_total * 64 : u.w0;
-  u.bias = md.packed + L.b_off[phase];
-  const int stride = is_val ? s.vstride : s.pstride;
-  float* a = is_val ? s.va : s.pa;
-  float* b = is_val ? s.vb : s.pb;
-  // phase 0 reads in0; phase i > 0 reads the buffer phase i-1 wrote
-  const float* in = phase == 0 ? s.in0 : ((phase & 1) ? a : b);
-  const int in_stride = phase == 0 ? AZ_IN0_STRIDE : stride;
-  u.ap = in + (lane & 15) * in_stride + (lane >> 4) * (kp >> 2) + kb_base * 4;
-  const bool last_layer = phase == L.n_layers - 1;
-  u.out_act = last_layer ? nullptr : ((phase & 1) ? b : a);
-  u.out_plain = is_val ? s.value : s.logits;
-  u.out_stride = last_layer ? (is_val ? AZ_MAX_ATOMS : AZ_MAX_ACTIONS) : stride;
-  u.out_np = np;
-  u.nout = L.nout[phase];
+  u.w0 = wbase + ((size_t)t0 * nkb_total + kb_base) * 64;
+  u.w1 = two ? u.w0 + (size_t)nkb_total * 64 : u.w0;
+  az_mlp_tile_in(md, s, is_val, phase, kb_base, u.ap_off, u.in_stride, u.kpq);
+  az_mlp_tile_out(md, s, is_val, phase, t0, u.o0);
+  if (rider) {
+    const int nkb2 = md.pol.kp[phase] >> 4;
+    u.w2 = reinterpret_cast<const az_f32x4*>(md.packed + md.pol.w_off[phase]) + (size_t)idx * nkb2 * 64;
+    u.nkb2 = nkb2;
+    az_mlp_tile_in(md, s, false, phase, 0, u.ap2_off, u.in_stride2, u.kpq2);
+    az_mlp_tile_out(md, s, false, phase, idx, u.o2);
+  } else {
+    u.w2 = u.w0;
+    u.nkb2 = 0;
+    u.ap2_off = u.ap_off;
+    u.in_stride2 = u.in_stride;
+    u.kpq2 = u.kpq;
+    u.o2 = u.o0;
+  }
   return u;
+}
+
+AZ_DEV MlpUnit az_mlp_no_unit(int P) {
+  MlpUnit none{};
+  none.flags = 0;
+  none.phase = P;
+  none.nkb = 0;
+  none.nkb2 = 0;
+  return none;
 }
 
 // The unit wave `wave` runs after (phase, idx, round); `start` asks for its first unit.
 template <int NWAVES>
 AZ_DEV MlpUnit az_mlp_next_unit(const ModelDev& md, const MlpLds& s, int P, int phase, int idx,
-                                int round, bool start, int wave, int lane) {
+                                int round, bool start, int wave) {
   if (!start) {
-    const MlpLayout& L0 = md.val;  // rounds are a property of the item's layer width
-    int n_val;
-    const int n = az_phase_items(md, phase, n_val);
-    const int kp = (idx < n_val ? L0.kp[phase] : md.pol.kp[phase]);
+    const PhaseShape ps = az_phase_shape(md, phase);
+    const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
     const int nrounds = ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
-    if (round + 1 < nrounds) return az_mlp_unit(md, s, phase, idx, round + 1, lane);
-    if (idx + NWAVES < n) return az_mlp_unit(md, s, phase, idx + NWAVES, 0, lane);
+    if (round + 1 < nrounds) return az_mlp_unit(md, s, phase, idx, round + 1);
+    if (idx + NWAVES < ps.n) return az_mlp_unit(md, s, phase, idx + NWAVES, 0);
     phase += 1;
+  } else {
+    phase = 0;
   }
-  for (; phase < P; ++phase) {
-    int n_val;
-    if (wave < az_phase_items(md, phase, n_val)) return az_mlp_unit(md, s, phase, wave, 0, lane);
+  for (; phase < P; ++phase)
+    if (wave < az_phase_shape(md, phase).n) return az_mlp_unit(md, s, phase, wave, 0);
+  return az_mlp_no_unit(P);
+}
+
+AZ_DEV int az_mlp_phases(const ModelDev& md) {
+  return md.pol.n_layers > md.val.n_layers ? md.pol.n_layers : md.val.n_layers;
+}
+
+// Writes the wave's unit sequence into the LDS table (every wave calls it; the caller
+// places a workgroup barrier before the first az_forward_tile).
+template <int NWAVES>
+AZ_DEV void az_mlp_table_build(const ModelDev& md, const MlpLds& s, int wave, int lane) {
+  const int P = az_mlp_phases(md);
+  int n = 0;
+  MlpUnit u = az_mlp_next_unit<NWAVES>(md, s, P, 0, 0, 0, true, wave);
+  while (u.flags & AZ_U_VALID) {
+    if (n < AZ_TABLE_UNITS && lane == 0)
+      *reinterpret_cast<MlpUnit*>(s.tab + (size_t)(wave * AZ_TABLE_UNITS + n) * AZ_UNIT_WORDS) = u;
+    ++n;
+    u = az_mlp_next_unit<NWAVES>(md, s, P, u.phase, u.idx, u.round, false, wave);
   }
-  MlpUnit none;
-  none.valid = false;
-  none.phase = P;
-  none.nkb = 0;
-  return none;
+  if (lane == 0) s.tab_n[wave] = n <= AZ_TABLE_UNITS ? n : -1;
+}
+
+// Descriptor `i` of the wave out of the table, in scalar registers: lane k reads word
+// k (one LDS access for the whole descriptor), then each word is broadcast from its lane.
+AZ_DEV MlpUnit az_mlp_table_fetch(const MlpLds& s, int wave, int i, int lane) {
+  static_assert(AZ_UNIT_WORDS <= 64, "one word per lane");
+  union {
+    MlpUnit u;
+    uint32_t w[AZ_UNIT_WORDS];
+  } x;
+  const uint32_t* src = s.tab + (size_t)(wave * AZ_TABLE_UNITS + i) * AZ_UNIT_WORDS;
+  const uint32_t mine = src[lane < AZ_UNIT_WORDS ? lane : 0];
+#pragma unroll
+  for (int k = 0; k < AZ_UNIT_WORDS; ++k) x.w[k] = __builtin_amdgcn_readlane(mine, k);
+  return x.u;
 }
 
 // Workgroup barrier that publishes LDS writes but leaves the weight prefetch (global
@@ -214,29 +322,53 @@ __device__ long long az_stamps[8][64];
   } while (0)
 #endif
 
-// Multiplies one unit out of the register slots W0/W1 and refills every slot, as soon
-// as it has been consumed, with the same k-block of the wave's NEXT unit (same-slot
-// refill: the prefetch distance is a whole unit, up to 32 KiB in flight per wave).
-AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpUnit& next, az_f32x4 (&W0)[AZ_SLOTS],
-                            az_f32x4 (&W1)[AZ_SLOTS], az_f32x4& acc0, az_f32x4& acc1, int lane,
-                            int wave_, int& stamp_i) {
-  if (u.first) {
-    acc0 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    acc1 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+// Register state of a wave between units: the weight slots.
+struct MlpRegs {
+  az_f32x4 W0[AZ_SLOTS], W1[AZ_SLOTS], W2[AZ_RIDER_SLOTS];
+};
+
+// One output tile's epilogue.  C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + r.
+AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& acc, float bn,
+                                 float* lds_base, int lane) {
+  const int n = o.n0 + n_off + (lane & 15);
+  float* out = lds_base + o.out_off;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) * 4 + r;
+    float y = acc[r] + bn;
+    if (o.act) {
+      y = az_swish(y);
+      out[row * o.out_stride + az_act_index(n, o.out_np)] = y;
+    } else if (n < o.nout) {
+      out[row * o.out_stride + n] = y;
+    }
   }
-  // The biases are fetched BEFORE the refill loads are issued: vector loads return in
-  // order, so a bias load issued after them would drain the whole prefetch.
-  float bias0 = 0.0f, bias1 = 0.0f;
-  if (u.last) {
-    bias0 = u.bias[u.t0 * 16 + (lane & 15)];
-    bias1 = u.two ? u.bias[(u.t0 + 1) * 16 + (lane & 15)] : 0.0f;
-  }
-  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Multiplies one unit out of the register slots and refills every slot, as soon as it
+// has been consumed, with the same k-block of the wave's NEXT unit (same-slot refill:
+// the prefetch distance is a whole unit, up to 32 KiB in flight per wave).  There is
+// one copy of this loop on purpose: a second instantiation (say, for single-tile
+// units) makes the register allocator keep two sets of weight slots and spill.
+AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, az_f32x4& acc0,
+                             az_f32x4& acc1, az_f32x4& acc2, const float* ap, const float* ap2,
+                             int lane) {
+  const az_f32x4* nw0 = next.w0 + lane;
+  const az_f32x4* nw1 = next.w1 + lane;
+  const az_f32x4* nw2 = next.w2 + lane;
+  const int nk = next.nkb - 1, nk2 = next.nkb2 > 0 ? next.nkb2 - 1 : 0;
+  az_f32x4 a_nxt = *reinterpret_cast<const az_f32x4*>(ap);
 #pragma unroll
   for (int kb = 0; kb < AZ_SLOTS; ++kb) {
     if (kb < u.nkb) {
-      const az_f32x4 a4 = *reinterpret_cast<const az_f32x4*>(u.ap + kb * 4);
-      const az_f32x4 b0 = W0[kb], b1 = W1[kb];
+      const az_f32x4 a4 = a_nxt;
+      // the A operands of the next k-block are read while this one multiplies
+      if (kb + 1 < AZ_SLOTS && kb + 1 < u.nkb)
+        a_nxt = *reinterpret_cast<const az_f32x4*>(ap + (kb + 1) * 4);
+      const az_f32x4 b0 = R.W0[kb];
+      // a single-tile unit multiplies its tile twice (w1 == w0; acc1 is ignored): a
+      // branch here would cost accumulator copies that drain the MFMA pipe per k-block
+      const az_f32x4 b1 = R.W1[kb];
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, acc0, 0, 0, 0);
@@ -246,62 +378,125 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpUnit& next, az_f32x4 (&W0
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, acc1, 0, 0, 0);
     }
+    if (kb < AZ_RIDER_SLOTS && kb < u.nkb2) {
+      const az_f32x4 a2 = *reinterpret_cast<const az_f32x4*>(ap2 + kb * 4);
+      const az_f32x4 b2 = R.W2[kb < AZ_RIDER_SLOTS ? kb : 0];
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b2.z, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b2.w, acc2, 0, 0, 0);
+    }
     // keep the refill right behind its slot's MFMAs: left alone, the scheduler sinks
-    // the loads to the end of the unit and the next unit then waits on fresh loads
+    // the loads to the end of the unit and the next unit then waits on fresh loads.
+    // Every slot is refilled unconditionally (a unit with fewer k-blocks re-reads its
+    // last one): with a fixed number of loads per unit the compiler can wait for a slot
+    // with the exact distance in the in-order load counter, whereas a conditional load
+    // forces it to drain the whole prefetch (vmcnt(0)) before every k-block.
     __builtin_amdgcn_sched_barrier(0);
-    if (kb < next.nkb) {
-      W0[kb] = next.w0[(size_t)kb * 64];
-      W1[kb] = next.w1[(size_t)kb * 64];
+    {
+      const int kc = kb < nk ? kb : nk;
+      R.W0[kb] = az_ldg4(nw0 + (size_t)kc * 64);
+      R.W1[kb] = az_ldg4(nw1 + (size_t)kc * 64);
+      if (kb < AZ_RIDER_SLOTS) {
+        const int kc2 = kb < nk2 ? kb : nk2;
+        R.W2[kb < AZ_RIDER_SLOTS ? kb : 0] = az_ldg4(nw2 + (size_t)kc2 * 64);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, az_f32x4& acc0,
+                            az_f32x4& acc1, float* lds_base, int lane, int wave_, int& stamp_i) {
+  const bool two = u.flags & AZ_U_TWO, last = u.flags & AZ_U_LAST, rider = u.flags & AZ_U_RIDER;
+  if (u.flags & AZ_U_FIRST) {
+    acc0 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc1 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  az_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // The biases are fetched BEFORE the refill loads are issued: vector loads return in
+  // order, so a bias load issued after them would drain the whole prefetch.
+  // All three are always loaded, for the same reason as the unconditional refills.
+  const float bias0 = az_ldg(u.o0.bias + (lane & 15));
+  const float bias1 = az_ldg(u.o0.bias + (two ? 16 : 0) + (lane & 15));
+  const float bias2 = az_ldg(u.o2.bias + (lane & 15));
+  const int lane_row = lane & 15, lane_q = lane >> 4;
+  const float* ap = lds_base + u.ap_off + lane_row * u.in_stride + lane_q * u.kpq;
+  const float* ap2 = lds_base + u.ap2_off + lane_row * u.in_stride2 + lane_q * u.kpq2;
+  __builtin_amdgcn_sched_barrier(0);
+  // Two waves share a SIMD.  Left alone they run their k-loops together (the matrix
+  // pipe is the bottleneck) and then their epilogues together (the vector ALU is).
+  // Priorities stagger them: the wave of the lower half multiplies first at the full
+  // MFMA rate, and its epilogue (lowest priority) then fills the issue slots between
+  // its partner's MFMAs.
+  if (wave_ < AZ_MLP_WAVES / 2)
+    __builtin_amdgcn_s_setprio(3);
+  else
+    __builtin_amdgcn_s_setprio(2);
+  az_mlp_unit_loop(u, next, R, acc0, acc1, acc2, ap, ap2, lane);
+  __builtin_amdgcn_s_setprio(0);
   AZ_STAMP_AT();
-  if (!u.last) return;
-  // epilogue.  C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + r.
+  if (rider) az_mlp_tile_epilogue(u.o2, 0, acc2, bias2, lds_base, lane);
+  if (!last) return;
+  az_mlp_tile_epilogue(u.o0, 0, acc0, bias0, lds_base, lane);
+  if (two) az_mlp_tile_epilogue(u.o0, 16, acc1, bias1, lds_base, lane);
+}
+
+// The wave's unit `i`: from the LDS table (TABLE and the table holds this wave's
+// sequence) or recomputed from the previous unit.
+template <int NWAVES, bool TABLE>
+AZ_DEV MlpUnit az_mlp_unit_at(const ModelDev& md, const MlpLds& s, int P, int wave, int lane,
+                              int n_tab, int i, const MlpUnit& prev, bool start) {
+  if (TABLE && n_tab >= 0) return i < n_tab ? az_mlp_table_fetch(s, wave, i, lane) : az_mlp_no_unit(P);
+  return az_mlp_next_unit<NWAVES>(md, s, P, prev.phase, prev.idx, prev.round, start, wave);
+}
+
+// Loads the weights of the wave's first unit; call before az_forward_tile (once, when
+// the calls wrap).
+template <int NWAVES, bool TABLE>
+AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
+  const int P = az_mlp_phases(md);
+  const int n_tab = TABLE ? __builtin_amdgcn_readfirstlane(s.tab_n[wave]) : -1;
+  const MlpUnit cur = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, az_mlp_no_unit(P), true);
+  // same order and count as a unit's refills
+  const int nk = cur.nkb > 0 ? cur.nkb - 1 : 0, nk2 = cur.nkb2 > 0 ? cur.nkb2 - 1 : 0;
+  if (!(cur.flags & AZ_U_VALID)) return;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half == 1 && !u.two) break;
-    const az_f32x4 acc = half ? acc1 : acc0;
-    const int n = (u.t0 + half) * 16 + (lane & 15);
-    const float bn = half ? bias1 : bias0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = (lane >> 4) * 4 + r;
-      float y = acc[r] + bn;
-      if (u.out_act) {
-        y = az_swish(y);
-        u.out_act[row * u.out_stride + az_act_index(n, u.out_np)] = y;
-      } else if (n < u.nout) {
-        u.out_plain[row * u.out_stride + n] = y;
-      }
+  for (int kb = 0; kb < AZ_SLOTS; ++kb) {
+    const int kc = kb < nk ? kb : nk;
+    R.W0[kb] = az_ldg4(cur.w0 + (size_t)kc * 64 + lane);
+    R.W1[kb] = az_ldg4(cur.w1 + (size_t)kc * 64 + lane);
+    if (kb < AZ_RIDER_SLOTS) {
+      const int kc2 = kb < nk2 ? kb : nk2;
+      R.W2[kb < AZ_RIDER_SLOTS ? kb : 0] = az_ldg4(cur.w2 + (size_t)kc2 * 64 + lane);
     }
   }
 }
 
 // Both networks on the 16 rows staged in s.in0 -> s.logits / s.value.  Called by all
-// NWAVES waves; ends with a workgroup barrier (LDS results visible to every thread).
-template <int NWAVES>
-AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane) {
-  const int P = md.pol.n_layers > md.val.n_layers ? md.pol.n_layers : md.val.n_layers;
-  az_f32x4 W0[AZ_SLOTS], W1[AZ_SLOTS];
+// NWAVES waves with the first unit's weights in R (az_forward_prime); ends with a
+// workgroup barrier (LDS results visible to every thread).  With WRAP the last unit
+// prefetches the first unit's weights again, so the next call needs no priming.
+template <int NWAVES, bool TABLE, bool WRAP>
+AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
+  const int P = az_mlp_phases(md);
+  const int n_tab = TABLE ? __builtin_amdgcn_readfirstlane(s.tab_n[wave]) : -1;
   az_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int stamp_i = 0;
   const int wave_ = wave;
   (void)wave_;
   AZ_STAMP_AT();
-  MlpUnit cur = az_mlp_next_unit<NWAVES>(md, s, P, 0, 0, 0, true, wave, lane);
-#pragma unroll
-  for (int kb = 0; kb < AZ_SLOTS; ++kb)
-    if (kb < cur.nkb) {
-      W0[kb] = cur.w0[(size_t)kb * 64];
-      W1[kb] = cur.w1[(size_t)kb * 64];
-    }
+  int ui = 0;
+  MlpUnit cur = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, az_mlp_no_unit(P), true);
   for (int phase = 0; phase < P; ++phase) {
-    while (cur.valid && cur.phase == phase) {
-      const MlpUnit next =
-          az_mlp_next_unit<NWAVES>(md, s, P, cur.phase, cur.idx, cur.round, false, wave, lane);
+    while ((cur.flags & AZ_U_VALID) && cur.phase == phase) {
+      MlpUnit next = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, ui + 1, cur, false);
+      ++ui;
+      MlpUnit pre = next;  // the unit whose weights the refills fetch (always a valid one)
+      if (!(next.flags & AZ_U_VALID))
+        pre = WRAP ? az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, cur, true) : cur;
       AZ_STAMP_AT();
-      az_mlp_run_unit(cur, next, W0, W1, acc0, acc1, lane, wave, stamp_i);
+      az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
       AZ_STAMP_AT();
       cur = next;
     }
