@@ -45,6 +45,10 @@ typedef __attribute__((ext_vector_type(4))) float az_f32x4;
 AZ_DEV az_f32x4 az_ldg4(const az_f32x4* p) {
   return *(const __attribute__((address_space(1))) az_f32x4*)p;
 }
+// element `lane` of a wave-uniform base: scalar base + 32-bit vector offset addressing
+AZ_DEV az_f32x4 az_ldg4_lane(const az_f32x4* base, int lane) {
+  return ((const __attribute__((address_space(1))) az_f32x4*)base)[(unsigned)lane];
+}
 AZ_DEV float az_ldg(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
 
 
@@ -327,21 +331,65 @@ struct MlpRegs {
   az_f32x4 W0[AZ_SLOTS], W1[AZ_SLOTS], W2[AZ_RIDER_SLOTS];
 };
 
+typedef __attribute__((ext_vector_type(2))) float az_f32x2;
+
+AZ_DEV az_f32x2 az_fma2(az_f32x2 a, az_f32x2 b, az_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+AZ_DEV az_f32x2 az_splat2(float v) { return az_f32x2{v, v}; }
+
+// az_swish (az_math.h) on two values at once: the same IEEE operations per element in
+// the same order, written on 2-vectors so that the multiplies, adds and fused
+// multiply-adds become packed instructions (half the vector-ALU issue slots).
+AZ_DEV az_f32x2 az_swish2(az_f32x2 x) {
+  const az_f32x2 t = -x;  // logistic(x) = 1 / (1 + exp(-x))
+  const bool nan0 = t.x != t.x, nan1 = t.y != t.y;
+  const bool ov0 = t.x > 88.72283935546875f, ov1 = t.y > 88.72283935546875f;
+  const bool un0 = t.x < -103.97208404541015625f, un1 = t.y < -103.97208404541015625f;
+  az_f32x2 xs;
+  xs.x = (nan0 | ov0 | un0) ? 0.0f : t.x;
+  xs.y = (nan1 | ov1 | un1) ? 0.0f : t.y;
+  const az_f32x2 kf = (xs * az_splat2(1.44269502162933349609375f) + az_splat2(12582912.0f)) - az_splat2(12582912.0f);
+  az_f32x2 r = az_fma2(kf, az_splat2(-0.693359375f), xs);
+  r = az_fma2(kf, az_splat2(2.12194440e-4f), r);
+  az_f32x2 p = az_splat2(1.9875691500e-4f);
+  p = az_fma2(p, r, az_splat2(1.3981999507e-3f));
+  p = az_fma2(p, r, az_splat2(8.3334519073e-3f));
+  p = az_fma2(p, r, az_splat2(4.1665795894e-2f));
+  p = az_fma2(p, r, az_splat2(1.6666665459e-1f));
+  p = az_fma2(p, r, az_splat2(5.0000001201e-1f));
+  p = az_fma2(p, r * r, r);
+  p = p + az_splat2(1.0f);
+  const int k0 = (int)kf.x, k1 = (int)kf.y;
+  const int k0a = k0 >> 1, k1a = k1 >> 1;
+  const az_f32x2 s1 = {az_pow2i(k0a), az_pow2i(k1a)};
+  const az_f32x2 s2 = {az_pow2i(k0 - k0a), az_pow2i(k1 - k1a)};
+  az_f32x2 e = (p * s1) * s2;
+  e.x = un0 ? 0.0f : e.x;
+  e.y = un1 ? 0.0f : e.y;
+  e.x = ov0 ? AZ_INF : e.x;
+  e.y = ov1 ? AZ_INF : e.y;
+  e.x = nan0 ? t.x : e.x;
+  e.y = nan1 ? t.y : e.y;
+  const az_f32x2 d = az_splat2(1.0f) + e;
+  const az_f32x2 l = {1.0f / d.x, 1.0f / d.y};
+  return x * l;
+}
+
 // One output tile's epilogue.  C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + r.
 AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& acc, float bn,
                                  float* lds_base, int lane) {
   const int n = o.n0 + n_off + (lane & 15);
-  float* out = lds_base + o.out_off;
+  float* out = lds_base + o.out_off + (lane >> 4) * 4 * o.out_stride;
+  if (o.act) {
+    const az_f32x2 lo = az_swish2(az_f32x2{acc.x, acc.y} + az_splat2(bn));
+    const az_f32x2 hi = az_swish2(az_f32x2{acc.z, acc.w} + az_splat2(bn));
+    float* q = out + az_act_index(n, o.out_np);
+    q[0] = lo.x;
+    q[o.out_stride] = lo.y;
+    q[2 * o.out_stride] = hi.x;
+    q[3 * o.out_stride] = hi.y;
+  } else if (n < o.nout) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = (lane >> 4) * 4 + r;
-    float y = acc[r] + bn;
-    if (o.act) {
-      y = az_swish(y);
-      out[row * o.out_stride + az_act_index(n, o.out_np)] = y;
-    } else if (n < o.nout) {
-      out[row * o.out_stride + n] = y;
-    }
+    for (int r = 0; r < 4; ++r) out[r * o.out_stride + n] = acc[r] + bn;
   }
 }
 
@@ -353,18 +401,17 @@ AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& ac
 AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, az_f32x4& acc0,
                              az_f32x4& acc1, az_f32x4& acc2, const float* ap, const float* ap2,
                              int lane) {
-  const az_f32x4* nw0 = next.w0 + lane;
-  const az_f32x4* nw1 = next.w1 + lane;
-  const az_f32x4* nw2 = next.w2 + lane;
   const int nk = next.nkb - 1, nk2 = next.nkb2 > 0 ? next.nkb2 - 1 : 0;
-  az_f32x4 a_nxt = *reinterpret_cast<const az_f32x4*>(ap);
+  az_f32x4 a[2];  // A operands of even / odd k-blocks
+  a[0] = *reinterpret_cast<const az_f32x4*>(ap);
 #pragma unroll
   for (int kb = 0; kb < AZ_SLOTS; ++kb) {
     if (kb < u.nkb) {
-      const az_f32x4 a4 = a_nxt;
-      // the A operands of the next k-block are read while this one multiplies
-      if (kb + 1 < AZ_SLOTS && kb + 1 < u.nkb)
-        a_nxt = *reinterpret_cast<const az_f32x4*>(ap + (kb + 1) * 4);
+      // The A operands of the next k-block are read while this one multiplies --
+      // unconditionally, so that the wait below can leave exactly this one read in
+      // flight; past the unit's last k-block it reads LDS that is not used.
+      if (kb + 1 < AZ_SLOTS) a[(kb + 1) & 1] = *reinterpret_cast<const az_f32x4*>(ap + (kb + 1) * 4);
+      const az_f32x4 a4 = a[kb & 1];
       const az_f32x4 b0 = R.W0[kb];
       // a single-tile unit multiplies its tile twice (w1 == w0; acc1 is ignored): a
       // branch here would cost accumulator copies that drain the MFMA pipe per k-block
@@ -395,11 +442,11 @@ AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, 
     __builtin_amdgcn_sched_barrier(0);
     {
       const int kc = kb < nk ? kb : nk;
-      R.W0[kb] = az_ldg4(nw0 + (size_t)kc * 64);
-      R.W1[kb] = az_ldg4(nw1 + (size_t)kc * 64);
+      R.W0[kb] = az_ldg4_lane(next.w0 + (size_t)kc * 64, lane);
+      R.W1[kb] = az_ldg4_lane(next.w1 + (size_t)kc * 64, lane);
       if (kb < AZ_RIDER_SLOTS) {
         const int kc2 = kb < nk2 ? kb : nk2;
-        R.W2[kb < AZ_RIDER_SLOTS ? kb : 0] = az_ldg4(nw2 + (size_t)kc2 * 64);
+        R.W2[kb < AZ_RIDER_SLOTS ? kb : 0] = az_ldg4_lane(next.w2 + (size_t)kc2 * 64, lane);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
