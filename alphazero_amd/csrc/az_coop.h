@@ -1,4 +1,4 @@
-// az_coop.h -- cooperative (16 threads per lane) form of the tree search.
+// az_coop.h -- cooperative (32 threads per lane) form of the tree search.
 //
 // The literal search walks root -> leaf re-evaluating the selection rule at every
 // level (d dependent round trips of loads + exp/div arithmetic per simulation) and
@@ -7,13 +7,14 @@
 // backup path.  So this form keeps, per node, the action the rule currently selects
 // together with the child it leads to (`sel`, in LDS), and restructures a simulation
 // as
-//   1. chase   : one thread per lane follows `sel` from the root -- one LDS read per
-//                level -- and records the path;
+//   1. chase   : one thread per lane follows `sel` from the root -- one dependent LDS
+//                read per level -- and records the path;
 //   2. evaluate: the caller's recurrent_fn (injected arrays, or env + MLP);
-//   3. update  : the 16 threads of the lane take one path node each: load the node's
-//                row (one round trip, all nodes in parallel), recompute the value
-//                chain from the leaf down to their node, apply the backup to their
-//                node, and re-evaluate the selection rule on the updated row.
+//   3. update  : the 32 threads of the lane take one path node each: load the node's
+//                row (one round trip, all nodes in parallel; the loads only need the
+//                path, so they can be issued before the evaluation), recompute the
+//                value chain from the leaf down to their node, apply the backup to
+//                their node, and re-evaluate the selection rule on the updated row.
 // Every floating-point operation is the same, on the same operands and in the same
 // order, as in the literal form (az_device.h), so the resulting tree is bit-identical.
 //
@@ -24,12 +25,13 @@
 
 #include "az_device.h"
 
-#define AZ_GROUP 16        // threads per lane
+#define AZ_GROUP 32        // threads per lane
 #define AZ_WG_LANES 16     // lanes per workgroup
 #define AZ_TREE_THREADS (AZ_GROUP * AZ_WG_LANES)
 
-// Words of LDS per lane: sel[N], edge_r[N], edge_d[N], path[S+1], pr[S], pd[S], hdr[8].
-__host__ __device__ inline int az_coop_lane_words(int S) { return 6 * S + 12; }
+// Words of LDS per lane: sel[N], edge_r[N], edge_d[N], path[S+1], pr[S], pd[S], hdr[8],
+// root_g[8], root_inv[8], root_tab[S].
+__host__ __device__ inline int az_coop_lane_words(int S) { return 7 * S + 28; }
 
 struct CoopLds {
   int32_t* sel;   // [N]   (action << 16) | (child + 1) currently selected at each node
@@ -38,7 +40,10 @@ struct CoopLds {
   int32_t* path;  // [S+1] node | action << 16 per path position
   float* pr;      // [S]   edge reward by path position
   float* pd;      // [S]   edge discount by path position
-  int32_t* hdr;   // [8]   depth, new node, parent, action, reward bits, discount bits
+  int32_t* hdr;   // [8]   depth, new node, parent, action, reward bits, discount bits, -, table row
+  float* root_g;      // [8] the root's Gumbel noise
+  float* root_inv;    // [8] the root's invalid-action mask
+  int32_t* root_tab;  // [S] the row of the considered-visits table this lane uses
   AZ_DEV CoopLds(float* base, int lane, int S) {
     float* p = base + (size_t)lane * az_coop_lane_words(S);
     const int N = S + 1;
@@ -49,6 +54,21 @@ struct CoopLds {
     pr = p + 4 * N;
     pd = p + 4 * N + S;
     hdr = reinterpret_cast<int32_t*>(p + 4 * N + 2 * S);
+    root_g = p + 4 * N + 2 * S + 8;
+    root_inv = root_g + 8;
+    root_tab = reinterpret_cast<int32_t*>(root_inv + 8);
+  }
+  // Copies of the root-only selection inputs (filled by az_coop_init): the root is
+  // re-selected every simulation, and reading these from global memory again would
+  // put two dependent round trips on the critical path of every update.
+  AZ_DEV RootCache root_cache(const SearchCtx& c) const {
+    RootCache rc;
+    rc.gumbel = root_g;
+    rc.invalid = root_inv;
+    rc.has_invalid = c.in.invalid_actions != nullptr;
+    rc.table_row = root_tab;
+    rc.table_nc = hdr[7];
+    return rc;
   }
 };
 
@@ -114,13 +134,15 @@ AZ_UNROLL_K
 
 // The action the search's selection rule picks at a node (root: depth 0).
 template <int AMAX>
-AZ_DEV int az_select_cached(const SearchCtx& c, int A, int b, bool root, const NodeRow<AMAX>& r) {
+AZ_DEV int az_select_cached(const SearchCtx& c, const CoopLds& s, int A, int b, bool root,
+                            const NodeRow<AMAX>& r) {
+  const RootCache rc = s.root_cache(c);
   if (c.d.variant == AZ_VARIANT_GUMBEL)
-    return root ? az_select_gumbel_root<AMAX>(c, A, b, r) : az_select_gumbel_interior<AMAX>(c, A, r);
+    return root ? az_select_gumbel_root<AMAX>(c, A, r, rc) : az_select_gumbel_interior<AMAX>(c, A, r);
   float noise[AMAX];
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
-  return az_select_puct<AMAX>(c, A, b, root ? 0 : 1, r, noise);
+  return az_select_puct<AMAX>(c, A, root ? 0 : 1, r, noise, rc);
 }
 
 AZ_DEV int32_t az_pack_sel(int action, int child) { return (action << 16) | (child + 1); }
@@ -129,11 +151,23 @@ AZ_DEV int32_t az_pack_sel(int action, int child) { return (action << 16) | (chi
 template <int AMAX, int KMAX>
 AZ_DEV void az_coop_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b) {
   const int A = l.A;
+  for (int a = 0; a < A; ++a) {
+    s.root_g[a] = c.in.root_gumbel ? c.in.root_gumbel[(size_t)b * A + a] : 0.0f;
+    s.root_inv[a] = c.in.invalid_actions ? c.in.invalid_actions[(size_t)b * A + a] : 0.0f;
+  }
+  s.hdr[7] = -1;
+  if (c.d.variant == AZ_VARIANT_GUMBEL && c.in.table) {
+    float nvalid = 0.0f;
+    for (int a = 0; a < A; ++a) nvalid = nvalid + (1.0f - s.root_inv[a]);
+    const int32_t nc = az_num_considered(c.d, nvalid);
+    for (int i = 0; i < c.d.S; ++i) s.root_tab[i] = c.in.table[(size_t)nc * c.d.S + i];
+    s.hdr[7] = nc;
+  }
   FullRow<AMAX, KMAX> f;
   NodeRow<AMAX> r;
   az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
   az_node_row<AMAX, KMAX>(f, A, l.K, r);
-  const int a = az_select_cached<AMAX>(c, A, b, true, r);
+  const int a = az_select_cached<AMAX>(c, s, A, b, true, r);
   int child = AZ_UNVISITED;
 AZ_UNROLL_A
   for (int i = 0; i < AZ_TRIP_A; ++i)
@@ -142,7 +176,9 @@ AZ_UNROLL_A
 }
 
 // Step 1 (one thread per lane): follow the cached selections from the root
-// (search.py:127-187) and record the path.  Returns the depth of the expanded node.
+// (search.py:127-187) and record the path.  Only the selection word is on the
+// dependent chain; the edge rewards / discounts of the path are gathered afterwards
+// by all threads (az_coop_fill_edges).  Returns the depth of the expanded node.
 AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
   int node = AZ_ROOT, dep = 0, act, nxt;
   for (;;) {
@@ -150,10 +186,6 @@ AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
     act = e >> 16;
     nxt = (e & 0xffff) - 1;
     s.path[dep] = node | (act << 16);
-    if (nxt >= 0) {
-      s.pr[dep] = s.edge_r[nxt];
-      s.pd[dep] = s.edge_d[nxt];
-    }
     dep += 1;
     if (nxt < 0 || dep >= max_depth) break;
     node = nxt;
@@ -163,6 +195,18 @@ AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
   s.hdr[2] = node;
   s.hdr[3] = act;
   return dep;
+}
+
+// Thread j of the lane's group copies the reward / discount of the path edges
+// j, j + AZ_GROUP, ... between recorded nodes (the edge into the evaluated node comes
+// from the evaluation itself).  Call after the chase is visible to the group and
+// before az_coop_apply, with a barrier on either side.
+AZ_DEV void az_coop_fill_edges(const CoopLds& s, int j, int dep) {
+  for (int q = j; q < dep - 1; q += AZ_GROUP) {
+    const int child = s.path[q + 1] & 0xffff;
+    s.pr[q] = s.edge_r[child];
+    s.pd[q] = s.edge_d[child];
+  }
 }
 
 // Largest path depth over the workgroup's lanes (uniform across the workgroup).
@@ -261,12 +305,28 @@ AZ_UNROLL_A
 AZ_UNROLL_K
     for (int k = 0; k < AZ_TRIP_K; ++k)
       if (k < K) lv[k] = ev_value[k];
-    for (int q = dep - 1; q > p; --q) {
-      const float r = q == dep - 1 ? reward : s.pr[q];
-      const float dsc = q == dep - 1 ? discount : s.pd[q];
+    // the edge into the evaluated node first, then the recorded edges q = dep-2 ... p+1,
+    // read from LDS four at a time so that a round trip covers four dependent steps
+    if (dep - 1 > p) {
 AZ_UNROLL_K
       for (int k = 0; k < AZ_TRIP_K; ++k)
-        if (k < K) lv[k] = r + dsc * lv[k];
+        if (k < K) lv[k] = reward + discount * lv[k];
+    }
+    for (int q = dep - 2; q > p; q -= 4) {
+      float rr[4], dd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qi = q - i > 0 ? q - i : 0;
+        rr[i] = s.pr[qi];
+        dd[i] = s.pd[qi];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (q - i > p) {
+AZ_UNROLL_K
+          for (int k = 0; k < AZ_TRIP_K; ++k)
+            if (k < K) lv[k] = rr[i] + dd[i] * lv[k];
+        }
     }
     const float cnt_child = (float)P.child_cnt;
 AZ_UNROLL_K
@@ -302,7 +362,7 @@ AZ_UNROLL_K
   // refresh the cached selection of this node
   NodeRow<AMAX> r;
   az_node_row<AMAX, KMAX>(f, A, K, r);
-  const int best = az_select_cached<AMAX>(c, A, b, p == 0, r);
+  const int best = az_select_cached<AMAX>(c, s, A, b, p == 0, r);
   int child = AZ_UNVISITED;
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)

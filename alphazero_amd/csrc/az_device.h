@@ -268,11 +268,40 @@ struct SearchCtx {
   az_search_inputs in;
 };
 
+// What only the ROOT selection reads besides the tree, for one lane: either the global
+// arrays themselves (az_root_inputs) or per-lane copies in LDS (az_coop.h).
+struct RootCache {
+  const float* gumbel;        // [A], Gumbel variant
+  const float* invalid;       // [A], meaningful when has_invalid
+  const int32_t* table_row;   // row `table_nc` of the considered-visits table
+  int32_t table_nc;           // -1: no row cached, index the global table
+  bool has_invalid;
+};
+
+// mctx_dist/_src/action_selection.py:168-174: how many actions the root considers.
+AZ_DEV int32_t az_num_considered(const az_search_desc& d, float nvalid) {
+  const int32_t num_valid = (int32_t)nvalid;
+  int32_t num_considered = d.max_num_considered < num_valid ? d.max_num_considered : num_valid;
+  return num_considered < 0 ? 0 : num_considered;
+}
+
+// The root inputs of lane b straight from the global arrays.
+AZ_DEV RootCache az_root_inputs(const SearchCtx& c, int A, int b) {
+  RootCache rc;
+  rc.has_invalid = c.in.invalid_actions != nullptr;
+  rc.gumbel = c.in.root_gumbel + (size_t)b * A;  // only read by the Gumbel variant
+  rc.invalid = c.in.invalid_actions + (size_t)b * A;
+  rc.table_row = c.in.table;
+  rc.table_nc = -1;
+  return rc;
+}
+
 // mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled).
 template <int AMAX>
-AZ_DEV int az_select_puct(const SearchCtx& c, int A, int b, int depth, const NodeRow<AMAX>& r,
-                          const float (&noise)[AMAX]) {
+AZ_DEV int az_select_puct(const SearchCtx& c, int A, int depth, const NodeRow<AMAX>& r,
+                          const float (&noise)[AMAX], const RootCache& rc) {
   const az_search_desc& d = c.d;
+  const bool use_mask = depth == 0 && rc.has_invalid;
   int32_t node_visit = r.node_visit;
   float pb_c = d.pb_c_init + az_logf((((float)node_visit + d.pb_c_base) + 1.0f) / d.pb_c_base);
   float probs[AMAX], value_score[AMAX], to_argmax[AMAX];
@@ -290,8 +319,7 @@ AZ_UNROLL_A
       float policy_score = ((sq * pb_c) * probs[a]) / (float)(r.vis[a] + 1);
       float v = (value_score[a] + policy_score) + noise[a];
       // action_selection.py:90: mask = root_invalid_actions * (depth == 0)
-      bool masked = depth == 0 && c.in.invalid_actions != nullptr &&
-                    c.in.invalid_actions[(size_t)b * A + a] != 0.0f;
+      bool masked = use_mask && rc.invalid[a] != 0.0f;
       to_argmax[a] = masked ? -AZ_INF : v;
     }
   return az_argmax<AMAX>(to_argmax, A);
@@ -299,29 +327,30 @@ AZ_UNROLL_A
 
 // mctx_dist/_src/action_selection.py:148-200
 template <int AMAX>
-AZ_DEV int az_select_gumbel_root(const SearchCtx& c, int A, int b, const NodeRow<AMAX>& r) {
+AZ_DEV int az_select_gumbel_root(const SearchCtx& c, int A, const NodeRow<AMAX>& r,
+                                 const RootCache& rc) {
   const az_search_desc& d = c.d;
   float cq[AMAX], score[AMAX];
   az_qtransform<AMAX>(d, A, r, cq);
-  const float* inv = c.in.invalid_actions ? c.in.invalid_actions + (size_t)b * A : nullptr;
   float nvalid = 0.0f;
   int32_t sim_index = 0;
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) {
-      nvalid = nvalid + (1.0f - (inv ? inv[a] : 0.0f));
+      nvalid = nvalid + (1.0f - (rc.has_invalid ? rc.invalid[a] : 0.0f));
       sim_index += r.vis[a];
     }
-  int32_t num_valid = (int32_t)nvalid;
-  int32_t num_considered = d.max_num_considered < num_valid ? d.max_num_considered : num_valid;
-  if (num_considered < 0) num_considered = 0;
+  const int32_t num_considered = az_num_considered(d, nvalid);
   if (sim_index > d.S - 1) sim_index = d.S - 1;
-  int32_t considered_visit = c.in.table[(size_t)num_considered * d.S + sim_index];
-  az_score_considered<AMAX>(considered_visit, c.in.root_gumbel + (size_t)b * A, r.logits, cq, r.vis,
-                            A, score);
+  int32_t considered_visit;
+  if (rc.table_nc == num_considered)
+    considered_visit = rc.table_row[sim_index];
+  else
+    considered_visit = c.in.table[(size_t)num_considered * d.S + sim_index];
+  az_score_considered<AMAX>(considered_visit, rc.gumbel, r.logits, cq, r.vis, A, score);
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
-    if (a < A && inv && inv[a] != 0.0f) score[a] = -AZ_INF;
+    if (a < A && rc.has_invalid && rc.invalid[a] != 0.0f) score[a] = -AZ_INF;
   return az_argmax<AMAX>(score, A);
 }
 
@@ -382,9 +411,9 @@ AZ_UNROLL_A
 AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
       }
-      act = az_select_puct<AMAX>(c, A, b, depth, r, noise);
+      act = az_select_puct<AMAX>(c, A, depth, r, noise, az_root_inputs(c, A, b));
     } else if (depth == 0) {
-      act = az_select_gumbel_root<AMAX>(c, A, b, r);
+      act = az_select_gumbel_root<AMAX>(c, A, r, az_root_inputs(c, A, b));
     } else {
       act = az_select_gumbel_interior<AMAX>(c, A, r);
     }

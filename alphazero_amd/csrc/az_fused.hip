@@ -121,7 +121,17 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
   const int kp = md.val.kp[0];
   for (int i = 0; i < md.obs_dim; ++i)
-    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = (obs[i] - md.mean[i]) / md.std[i];
+    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = (obs[i] - s.norm_mean[i]) / s.norm_std[i];
+}
+
+// Kernel prologue: zeroes the first layer's input rows and copies the normaliser into
+// LDS (the caller places a workgroup barrier before the first az_store_obs).
+AZ_DEV void az_stage_inputs(const ModelDev& md, const MlpLds& s, int tid, int nthreads) {
+  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += nthreads) s.in0[i] = 0.0f;
+  for (int i = tid; i < md.obs_dim; i += nthreads) {
+    s.norm_mean[i] = md.mean[i];
+    s.norm_std[i] = md.std[i];
+  }
 }
 
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   MlpLds s(lds, md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
+  az_stage_inputs(md, s, tid, blockDim.x);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   MlpLds s(lds, md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
+  az_stage_inputs(md, s, tid, blockDim.x);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) {
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   const int b = blockIdx.x * 16 + tid;
   const bool active = tid < 16 && b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, d.S + 1, d.A, d.K);
-  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
+  az_stage_inputs(md, s, tid, blockDim.x);
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   MlpRegs regs;
@@ -280,73 +290,156 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
 }
 
 
-// The fused search in the cooperative form (az_coop.h).  Threads 0..255 are the tree
-// threads (16 lanes x 16 threads); all AZ_MLP_WAVES waves run the networks.
+#ifdef AZ_STAMP
+// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation.
+__device__ long long az_sim_stamps[64][16];
+#define AZ_SIM_STAMP(k)                                                                        \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && j == 0 && ln == 0 && sim < 64) az_sim_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define AZ_SIM_STAMP(k) \
+  do {                  \
+  } while (0)
+#endif
+
+// A copy of `v` the compiler cannot trace back: whatever is derived from it (here the
+// per-lane base addresses of the tree arrays) is recomputed where it is used instead of
+// being hoisted out of the simulation loop and kept in registers across the MLP phase,
+// whose weight slots need the registers.
+AZ_DEV int az_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// The fused search in the cooperative form (az_coop.h): all threads are tree threads
+// (16 lanes x 32 threads) and all AZ_MLP_WAVES waves run the networks.
 template <int AMAX, int KMAX>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
-    SearchCtx c, az_tree t, ModelDev md, unsigned long long* sum_depth) {
+    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
   MlpLds s(lds, md.pol_kp, md.val_kp);
   float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const bool tree_thread = tid < AZ_TREE_THREADS;
-  const int ln = (tid >> 4) & (AZ_WG_LANES - 1), j = tid & (AZ_GROUP - 1);
+  // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
+  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share wave 0
+  // (the last wave takes position 0: the root's selection rule and the interior one are
+  // different code, and this way they run in different waves at the same time)
+  const int ln = tid & (AZ_WG_LANES - 1), j = (tid / AZ_WG_LANES + 1) & (AZ_GROUP - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
-  const bool active = tree_thread && b < d.B;
+  const bool active = b < d.B;
   const bool leader = active && j == 0;
-  Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
   CoopLds cs(tree_lds, ln, S);
-  for (int i = tid; i < 16 * AZ_IN0_STRIDE; i += blockDim.x) s.in0[i] = 0.0f;
-  if (tree_thread && j == 0) {
+  // With room in LDS, the lane's environment states live there too ([N][5] words: the
+  // state and the step counter); global memory keeps a write-through copy for the caller.
+  float* emb = emb_in_lds ? tree_lds + AZ_WG_LANES * az_coop_lane_words(S) + ln * (S + 1) * 5 : nullptr;
+  az_stage_inputs(md, s, tid, blockDim.x);
+  if (j == 0) {
     cs.hdr[0] = -1;
-    if (active) az_coop_init<AMAX, KMAX>(c, l, cs, b);
+    if (active) {
+      Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
+      az_coop_init<AMAX, KMAX>(c, l, cs, b);
+      if (emb) {
+        for (int i = 0; i < 4; ++i) emb[i] = l.es[i];
+        emb[4] = az_u2f((uint32_t)l.et[0]);
+      }
+    }
   }
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
-  MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
-  long long depth_sum = 0;
+  int depth_sum = 0;
   for (int sim = 0; sim < S; ++sim) {
     EnvState st;
-    if (leader) {
-      depth_sum += az_coop_chase(cs, sim, d.max_depth);
+    AZ_SIM_STAMP(0);
+    MlpRegs regs;
+    constexpr bool kPrefetch = sizeof(CoopPos<AMAX, KMAX>) <= 32 * 4;
+    CoopPos<AMAX, KMAX> P0;
+    int dep, newn;
+    {
+      Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
+      if (leader) {
+        depth_sum += az_coop_chase(cs, sim, d.max_depth);
+        AZ_SIM_STAMP(1);
+        const int parent = cs.hdr[2], action = cs.hdr[3];
+        if (emb) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) st.s[i] = emb[parent * 5 + i];
+          st.time = (int32_t)az_f2u(emb[parent * 5 + 4]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
+          st.time = l.et[parent];
+        }
+        EnvOut o;
+        float reward, discount;
+        az_model_env_step(md, st, action, o, reward, discount);
+        if (emb) {
+          const int nn = cs.hdr[1];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) emb[nn * 5 + i] = st.s[i];
+          emb[nn * 5 + 4] = az_u2f((uint32_t)st.time);
+        }
+        cs.hdr[4] = (int32_t)az_f2u(reward);
+        cs.hdr[5] = (int32_t)az_f2u(discount);
+        az_store_obs(md, s, ln, o.obs);
+      }
+      // The first unit's weights are requested here: the waves without leader threads get
+      // here at once, so their weights arrive while the leaders walk the tree and step the
+      // environment, and the leaders' wave is not held up behind everybody's requests.
+      // The weight registers are not kept across the update below, which needs them.
+      az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+      AZ_SIM_STAMP(2);
+      __syncthreads();
+      AZ_SIM_STAMP(3);
+      // The path is known now, and the rows the update will need depend on the path only:
+      // gather the path's edge rewards and (when a row fits in a few registers) issue
+      // the row loads before the networks run, so that their latency hides behind the MLPs.
+      dep = cs.hdr[0];
+      newn = cs.hdr[1];
+      if (active) az_coop_fill_edges(cs, j, dep);
+      if (kPrefetch && active && j <= dep) az_coop_load<AMAX, KMAX>(l, cs, j, dep, newn, P0);
+    }
+    az_forward_tile<AZ_MLP_WAVES, true, false>(md, s, wave, lane, regs);
+    AZ_SIM_STAMP(4);
+    {
+      Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
+      const int maxdep = az_coop_max_depth(tree_lds, S);
       const int parent = cs.hdr[2], action = cs.hdr[3];
+      const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
+      if (leader) {
+        if (emb) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
-      st.time = l.et[parent];
-      EnvOut o;
-      float reward, discount;
-      az_model_env_step(md, st, action, o, reward, discount);
-      cs.hdr[4] = (int32_t)az_f2u(reward);
-      cs.hdr[5] = (int32_t)az_f2u(discount);
-      az_store_obs(md, s, ln, o.obs);
-    }
-    __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES, true, true>(md, s, wave, lane, regs);
-    const int maxdep = az_coop_max_depth(tree_lds, S);
-    const int dep = cs.hdr[0], newn = cs.hdr[1], parent = cs.hdr[2], action = cs.hdr[3];
-    const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
-    if (leader) {
+          for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = emb[newn * 5 + i];
+          l.et[newn] = (int32_t)az_f2u(emb[newn * 5 + 4]);
+        } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = st.s[i];
-      l.et[newn] = st.time;
-    }
-    for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
-      const int p = j + it * AZ_GROUP;
-      const bool mine = active && p <= dep;
-      CoopPos<AMAX, KMAX> P;
-      if (mine) az_coop_load<AMAX, KMAX>(l, cs, p, dep, newn, P);
-      __syncthreads();
-      if (mine)
-        az_coop_apply<AMAX, KMAX>(c, l, cs, b, p, dep, newn, parent, action,
-                                  s.logits + ln * AZ_MAX_ACTIONS, s.value + ln * AZ_MAX_ATOMS,
-                                  reward, discount, P);
-      __syncthreads();
+          for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = st.s[i];
+          l.et[newn] = st.time;
+        }
+      }
+      for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
+        const int p = j + it * AZ_GROUP;
+        const bool mine = active && p <= dep;
+        CoopPos<AMAX, KMAX> P;
+        if (kPrefetch && it == 0) {
+          P = P0;  // loaded before any of this simulation's updates: no barrier needed
+        } else {
+          if (mine) az_coop_load<AMAX, KMAX>(l, cs, p, dep, newn, P);
+          __syncthreads();  // every load of the iteration before any of its updates
+        }
+        AZ_SIM_STAMP(6 + 3 * (it < 2 ? it : 2));
+        if (mine)
+          az_coop_apply<AMAX, KMAX>(c, l, cs, b, p, dep, newn, parent, action,
+                                    s.logits + ln * AZ_MAX_ACTIONS, s.value + ln * AZ_MAX_ATOMS,
+                                    reward, discount, P);
+        __syncthreads();
+        AZ_SIM_STAMP(7 + 3 * (it < 2 ? it : 2));
+      }
     }
   }
-  if (tree_thread) az_add_depth(sum_depth, depth_sum);
+  az_add_depth(sum_depth, (long long)depth_sum);
 }
 
 extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
@@ -364,13 +457,17 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, lds)) {
-    const size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+    const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
+    const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
+    if (emb_in_lds) lds2 += emb_bytes;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
         if (int rc = az_set_lds((const void*)k_search_fused_coop<AMAX, KMAX>, lds2)) return rc;
         k_search_fused_coop<AMAX, KMAX>
             <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
-               (hipStream_t)stream>>>(c, *t, md, reinterpret_cast<unsigned long long*>(sum_depth));
+               (hipStream_t)stream>>>(c, *t, md, emb_in_lds,
+                                      reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;
       } else {
@@ -394,6 +491,11 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
 extern "C" int az_debug_read_stamps(long long* host_out) {
   AZ_HIP(hipDeviceSynchronize());
   AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_stamps), sizeof(long long) * 8 * 64));
+  return AZ_OK;
+}
+extern "C" int az_debug_read_sim_stamps(long long* host_out) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_sim_stamps), sizeof(long long) * 64 * 16));
   return AZ_OK;
 }
 #endif

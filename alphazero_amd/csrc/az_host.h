@@ -31,6 +31,11 @@ bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes);
 // bound is a generic path with run-time loops.
 template <typename F>
 static int az_dispatch_ak(int A, int K, F&& f) {
+#ifdef AZ_NARROW_BUILD
+  // diagnostic builds only: one instantiation (A <= 2, K == 1) to keep compile times short
+  if (A <= 2 && K == 1) return f.template operator()<2, 1>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A <= 2 and K == 1 only");
+#else
 #define AZ_K_CASES(AM)                                  \
   if (K == 1) return f.template operator()<AM, 1>();    \
   if (K <= 8) return f.template operator()<AM, 8>();    \
@@ -41,6 +46,7 @@ static int az_dispatch_ak(int A, int K, F&& f) {
   if (A <= 8) { AZ_K_CASES(8) }
   AZ_K_CASES(AZ_MAX_ACTIONS)
 #undef AZ_K_CASES
+#endif
 }
 
 // wave-level sum of a per-thread counter, one atomic per wave

@@ -104,17 +104,19 @@ AZ_DEV int az_act_index(int k, int kp) { return (k & 3) * (kp >> 2) + (k >> 2); 
 
 // LDS floats of the network scratch: in0 [16][AZ_IN0_STRIDE], two ping-pong activation buffers
 // per network, logits [16][AZ_MAX_ACTIONS], values [16][AZ_MAX_ATOMS], the unit table
-// [AZ_MLP_WAVES][AZ_TABLE_UNITS][AZ_UNIT_WORDS] and its per-wave counts.
+// [AZ_MLP_WAVES][AZ_TABLE_UNITS][AZ_UNIT_WORDS], its per-wave counts, and the observation
+// normaliser's mean and standard deviation.
 __host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp) {
   return 16 * AZ_IN0_STRIDE + 2 * 16 * az_act_stride(pol_kp) + 2 * 16 * az_act_stride(val_kp) +
          16 * AZ_MAX_ACTIONS + 16 * AZ_MAX_ATOMS +
-         AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS + 16;
+         AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS + 16 + 2 * AZ_IN0_STRIDE;
 }
 
 struct MlpLds {
   float *base, *in0, *pa, *pb, *va, *vb, *logits, *value;
   uint32_t* tab;   // unit table; 16-byte aligned because every region is a multiple of 4 floats
   int32_t* tab_n;  // units of each wave in the table, or -1 when they do not fit
+  float *norm_mean, *norm_std;  // [obs_dim] copies of the observation normaliser
   int pstride, vstride;
   AZ_DEV MlpLds(float* base_, int pol_kp, int val_kp) {
     base = base_;
@@ -129,6 +131,8 @@ struct MlpLds {
     value = logits + 16 * AZ_MAX_ACTIONS;
     tab = reinterpret_cast<uint32_t*>(value + 16 * AZ_MAX_ATOMS);
     tab_n = reinterpret_cast<int32_t*>(tab + AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS);
+    norm_mean = reinterpret_cast<float*>(tab_n + 16);
+    norm_std = norm_mean + AZ_IN0_STRIDE;
   }
 };
 

@@ -98,7 +98,7 @@ AZ_UNROLL_K
   az_add_depth(sum_depth, depth_sum);
 }
 
-// The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 16
+// The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 32
 // threads per lane, cached selections and the path in LDS.
 template <int AMAX, int KMAX>
 __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
@@ -106,7 +106,9 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
-  const int tid = threadIdx.x, ln = tid >> 4, j = tid & (AZ_GROUP - 1);
+  // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
+  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share wave 0
+  const int tid = threadIdx.x, ln = tid & (AZ_WG_LANES - 1), j = tid / AZ_WG_LANES;
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
@@ -132,6 +134,7 @@ AZ_UNROLL_K
     __syncthreads();
     const int maxdep = az_coop_max_depth(lds, S);
     const int dep = s.hdr[0], newn = s.hdr[1], parent = s.hdr[2], action = s.hdr[3];
+    if (active) az_coop_fill_edges(s, j, dep);
     for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
       const int p = j + it * AZ_GROUP;
       const bool mine = active && p <= dep;
