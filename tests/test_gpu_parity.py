@@ -181,6 +181,7 @@ def test_forward_and_recurrent_step_vs_oracle(hip, oracle, env_id):
 
 FUSED_CASES = [
     ("CartPole-v1", "gumbel", 40, 16, 1, {}),
+    ("CartPole-v1", "gumbel", 20, 256, 1, {}),   # the S of the largest baseline configuration
     ("CartPole-v1", "muzero", 16, 12, 1, {}),
     ("CartPole-v1", "gumbel", 16, 12, 1, dict(qt_kwargs=dict(use_mixed_value=False))),
     ("MountainCar-v0", "muzero", 16, 12, 1, {}),
@@ -217,9 +218,10 @@ def test_fused_equals_callback_path(hip):
     dict(variant="gumbel", B=20, S=40, A=2, K=1, max_depth=5),
     dict(variant="gumbel", B=20, S=40, A=2, K=1, max_depth=1),
     dict(variant="gumbel", B=10, S=40, A=8, K=8),
+    dict(variant="gumbel", B=24, S=256, A=2, K=1),   # paths deeper than one 32-thread group
 ], ids=_ids)
 def test_literal_and_cooperative_tree_kernels_agree(hip, kw, monkeypatch):
-    """The literal one-thread-per-lane kernel and the cooperative 16-threads-per-lane kernel
+    """The literal one-thread-per-lane kernel and the cooperative 32-threads-per-lane kernel
     (cached selections in LDS) build bit-identical trees, and both equal the CPU checker."""
     case = _case(kw, seed=51)
     coop = hip.run_policy_hip(case, "persistent")
