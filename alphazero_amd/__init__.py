@@ -18,6 +18,7 @@ from .search import InjectedRecurrentFn, search
 from .seq_halving import get_sequence_of_considered_visits, get_table_of_considered_visits
 from .tree import SearchSummary, Tree, infer_batch_size
 from . import envs
+from . import replay_buffers
 
 __version__ = "0.1.0"
 

@@ -68,12 +68,37 @@ class Model(C.Structure):
                 ("packed", C.c_void_p), ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p)]
 
 
+class Replay(C.Structure):
+    """az_replay (include/az_replay.h)."""
+    _fields_ = [("rows", C.c_void_p), ("priority", C.c_void_p), ("weight", C.c_void_p),
+                ("cum", C.c_void_p), ("partial", C.c_void_p), ("owner", C.c_void_p),
+                ("cap", C.c_int32), ("D", C.c_int32)]
+
+
+class ReplayState(C.Structure):
+    """az_replay_state (include/az_replay.h)."""
+    _fields_ = [("head", C.c_int32), ("insert_position", C.c_int32),
+                ("sample_position", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _F = C.c_float
+_K2 = C.POINTER(C.c_uint32 * 2)
 
-# name -> (restype, argtypes); every symbol declared in include/az_mcts.h
+# name -> (restype, argtypes); every symbol declared in include/az_mcts.h and az_replay.h
 SIGNATURES = {
+    "az_replay_partial_floats": (C.c_int64, [_I]),
+    "az_replay_init": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P]),
+    "az_replay_insert": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _I, _P]),
+    "az_replay_sample_prioritized": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _K2, _F,
+                                               _I, _P, _P, _P]),
+    "az_replay_sample_uniform": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _K2, _I, _P,
+                                           _P, _P]),
+    "az_replay_set_priorities": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _P, _I,
+                                           _P]),
+    "az_replay_export": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _P]),
+    "az_replay_scan": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _P, _P]),
     "az_last_error": (C.c_char_p, []),
     "az_device_count": (C.c_int, []),
     "az_build_arch": (C.c_char_p, []),

@@ -1,0 +1,418 @@
+// az_replay.hip -- the replay queues of the learner side on the GPU (include/az_replay.h).
+// Part of libaz_mcts.so (gfx950 only); built with -ffp-contract=off.
+//
+// HBM-bound byte work: rows are a ring [cap, D] (no roll on insert), the priority and
+// weight columns live in their own contiguous arrays (a sampling pass streams 4 bytes
+// per row, not a cache line per row), and the prefix sums run in the fixed association
+// order of az_replay.h so that the CPU checker reproduces every bit.
+#include <hip/hip_runtime.h>
+
+#include "az_host.h"
+#include "az_math.h"
+#include "../../include/az_replay.h"
+
+static inline int az_scan_chunks(int cap) { return (cap + AZ_SCAN_CHUNK - 1) / AZ_SCAN_CHUNK; }
+
+extern "C" int64_t az_replay_partial_floats(int32_t cap) {
+  if (cap < 1) return -1;
+  return 2 * (int64_t)az_scan_chunks(cap) + 8;
+}
+
+static int az_check_replay(const az_replay* r, const az_replay_state* st) {
+  if (!r || !st) return az_fail(AZ_ERR_INVALID, "null replay descriptor or state");
+  if (r->cap < 1 || r->D < 3) return az_fail(AZ_ERR_INVALID, "replay needs cap >= 1 and D >= 3");
+  if (!r->rows || !r->priority || !r->weight || !r->cum || !r->partial || !r->owner)
+    return az_fail(AZ_ERR_INVALID, "replay descriptor has null buffers");
+  if (st->head < 0 || st->head >= r->cap || st->insert_position < 0 ||
+      st->insert_position > r->cap || st->sample_position < 0)
+    return az_fail(AZ_ERR_INVALID, "replay state out of range");
+  return AZ_OK;
+}
+
+AZ_DEV int az_phys(int logical, int head, int cap) {
+  const int p = head + logical;
+  return p >= cap ? p - cap : p;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_replay_init(az_replay r) {
+  const int64_t total = (int64_t)r.cap * r.D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x)
+    r.rows[i] = 0.0f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r.cap; i += gridDim.x * blockDim.x) {
+    r.priority[i] = 0.0f;
+    r.weight[i] = 0.0f;
+    r.owner[i] = -1;
+  }
+}
+
+extern "C" int az_replay_init(const az_replay* r, az_replay_state* st, void* stream) {
+  if (!r || !st) return az_fail(AZ_ERR_INVALID, "null replay descriptor or state");
+  st->head = st->insert_position = st->sample_position = 0;
+  if (int rc = az_check_replay(r, st)) return rc;
+  k_replay_init<<<dim3(1024), dim3(256), 0, (hipStream_t)stream>>>(*r);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// one workgroup of 64 threads per inserted row
+__global__ void k_replay_insert(az_replay r, const float* __restrict__ update, int n, int pos,
+                                int head) {
+  const int row = blockIdx.x;
+  const int p = az_phys(pos + row, head, r.cap);
+  const float* src = update + (size_t)row * r.D;
+  float* dst = r.rows + (size_t)p * r.D;
+  for (int c = threadIdx.x; c < r.D; c += blockDim.x) dst[c] = src[c];
+  if (threadIdx.x == 0) {
+    r.priority[p] = src[r.D - 2];
+    r.weight[p] = src[r.D - 1];
+  }
+}
+
+extern "C" int az_replay_insert(const az_replay* r, az_replay_state* st, const float* update,
+                                int32_t n, void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!update || n < 1) return az_fail(AZ_ERR_INVALID, "bad insert arguments");
+  if (n > r->cap)
+    return az_fail(AZ_ERR_INVALID,
+                   "Trying to insert a batch of samples larger than the maximum replay size. "
+                   "num_samples: %d, max replay size %d", n, r->cap);
+  // replay_buffers.py:143-153.  roll <= 0 drops the -roll oldest rows: the ring's head
+  // moves forward instead of the data moving backward.
+  int position = st->insert_position;
+  const int roll = r->cap - position - n < 0 ? r->cap - position - n : 0;
+  st->head = (st->head - roll) % r->cap;
+  position += roll;
+  k_replay_insert<<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(*r, update, n, position, st->head);
+  AZ_LAUNCH_CHECK();
+  st->insert_position = (position + n) % (r->cap + 1);
+  st->sample_position = st->sample_position + roll > 0 ? st->sample_position + roll : 0;
+  return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// prefix sums in the contract's order.  The scanned value of logical row i is the masked
+// priority (i < n_valid ? priority : 0), divided by *divisor when divisor is non-null.
+AZ_DEV float az_scan_value(const az_replay& r, int i, int n_valid, int head, const float* divisor) {
+  float v = 0.0f;
+  if (i < r.cap && i < n_valid) v = r.priority[az_phys(i, head, r.cap)];
+  if (divisor) v = v / *divisor;
+  return v;
+}
+
+// The run of AZ_SCAN_T values of thread t in chunk k: inclusive sums left to right.
+AZ_DEV void az_scan_run(const az_replay& r, int chunk, int t, int n_valid, int head,
+                        const float* divisor, float (&incl)[AZ_SCAN_T]) {
+  const int base = chunk * AZ_SCAN_CHUNK + t * AZ_SCAN_T;
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < AZ_SCAN_T; ++j) {
+    const float v = az_scan_value(r, base + j, n_valid, head, divisor);
+    s = j == 0 ? v : s + v;
+    incl[j] = s;
+  }
+}
+
+// Left-to-right exclusive sums of the workgroup's run totals (in LDS), by one thread:
+// the order is the contract, and 256 dependent adds per 4096 rows are cheap.
+AZ_DEV float az_scan_runs(float* tot, float* off, int t) {
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < AZ_SCAN_B; ++i) {
+      off[i] = s;
+      s = s + tot[i];
+    }
+    // chunk total as the contract defines it: last run offset + last run total
+    tot[AZ_SCAN_B] = off[AZ_SCAN_B - 1] + tot[AZ_SCAN_B - 1];
+  }
+  __syncthreads();
+  return off[t];
+}
+
+// pass A: chunk totals
+__global__ __launch_bounds__(AZ_SCAN_B) void k_scan_totals(az_replay r, int n_valid, int head,
+                                                           const float* divisor,
+                                                           float* __restrict__ chunk_tot) {
+  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+  float incl[AZ_SCAN_T];
+  az_scan_run(r, blockIdx.x, threadIdx.x, n_valid, head, divisor, incl);
+  tot[threadIdx.x] = incl[AZ_SCAN_T - 1];
+  az_scan_runs(tot, off, threadIdx.x);
+  if (threadIdx.x == 0) chunk_tot[blockIdx.x] = tot[AZ_SCAN_B];
+}
+
+// level 2: chunk offsets left to right (one thread); also the grand total, which by the
+// contract is cum[cap - 1]... computed by pass B's formula for the last row
+__global__ void k_scan_chunks(const float* __restrict__ chunk_tot, int nchunks,
+                              float* __restrict__ chunk_off) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < nchunks; ++i) {
+      chunk_off[i] = s;
+      s = s + chunk_tot[i];
+    }
+  }
+}
+
+// pass B: cum[i] = (chunk_off + run_off) + incl; optionally the importance weights
+// 1 / (n_valid * p + 1e-10)^beta of every row with their maximum (as uint bits: the
+// weights are positive), replay_buffers.py:329-330.
+__global__ __launch_bounds__(AZ_SCAN_B) void k_scan_final(az_replay r, int n_valid, int head,
+                                                          const float* divisor,
+                                                          const float* __restrict__ chunk_off,
+                                                          float* __restrict__ cum, int with_weights,
+                                                          float beta, unsigned int* wmax_bits) {
+  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+  __shared__ unsigned int smax;
+  float incl[AZ_SCAN_T];
+  const int t = threadIdx.x;
+  if (t == 0) smax = 0u;
+  az_scan_run(r, blockIdx.x, t, n_valid, head, divisor, incl);
+  tot[t] = incl[AZ_SCAN_T - 1];
+  const float run_off = az_scan_runs(tot, off, t);
+  const float base_off = chunk_off[blockIdx.x] + run_off;
+  const int base = blockIdx.x * AZ_SCAN_CHUNK + t * AZ_SCAN_T;
+  unsigned int mx = 0u;
+#pragma unroll
+  for (int j = 0; j < AZ_SCAN_T; ++j) {
+    const int i = base + j;
+    if (i < r.cap) {
+      cum[i] = base_off + incl[j];
+      if (with_weights) {
+        const float p = az_scan_value(r, i, n_valid, head, divisor);
+        const float w = 1.0f / az_powf((float)n_valid * p + 1e-10f, beta);
+        r.weight[az_phys(i, head, r.cap)] = w;
+        const unsigned int b = az_f2u(w);
+        mx = b > mx ? b : mx;
+      }
+    }
+  }
+  if (with_weights) {
+    atomicMax(&smax, mx);
+    __syncthreads();
+    if (t == 0) atomicMax(wmax_bits, smax);
+  }
+}
+
+__global__ void k_weights_normalise(az_replay r, const unsigned int* __restrict__ wmax_bits) {
+  const float wmax = az_u2f(*wmax_bits);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r.cap; i += gridDim.x * blockDim.x)
+    r.weight[i] = r.weight[i] / wmax;
+}
+
+// Runs the scan of (masked priority [/ divisor]) into r.cum; partial[0..nc) chunk totals,
+// partial[nc..2nc) chunk offsets.
+static int az_scan_launch(const az_replay* r, const az_replay_state* st, const float* divisor,
+                          int with_weights, float beta, unsigned int* wmax_bits, bool need_cum,
+                          hipStream_t s) {
+  const int nc = az_scan_chunks(r->cap);
+  float* chunk_tot = r->partial;
+  float* chunk_off = r->partial + nc;
+  k_scan_totals<<<dim3(nc), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, divisor,
+                                                      chunk_tot);
+  AZ_LAUNCH_CHECK();
+  k_scan_chunks<<<dim3(1), dim3(64), 0, s>>>(chunk_tot, nc, chunk_off);
+  AZ_LAUNCH_CHECK();
+  if (need_cum) {
+    k_scan_final<<<dim3(nc), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, divisor,
+                                                       chunk_off, r->cum, with_weights, beta,
+                                                       wmax_bits);
+    AZ_LAUNCH_CHECK();
+  }
+  return AZ_OK;
+}
+
+// total[0] = cum[cap - 1] of the scan whose chunk totals / offsets are in `partial`:
+// the last row's formula needs its run, so it is recomputed by one workgroup.
+__global__ __launch_bounds__(AZ_SCAN_B) void k_scan_last(az_replay r, int n_valid, int head,
+                                                         const float* divisor,
+                                                         const float* __restrict__ chunk_off,
+                                                         float* __restrict__ total) {
+  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+  float incl[AZ_SCAN_T];
+  const int chunk = (r.cap - 1) / AZ_SCAN_CHUNK, t = threadIdx.x;
+  az_scan_run(r, chunk, t, n_valid, head, divisor, incl);
+  tot[t] = incl[AZ_SCAN_T - 1];
+  const float run_off = az_scan_runs(tot, off, t);
+  const int within = (r.cap - 1) - chunk * AZ_SCAN_CHUNK;
+  if (t == within / AZ_SCAN_T) total[0] = (chunk_off[chunk] + run_off) + incl[within % AZ_SCAN_T];
+}
+
+// ---------------------------------------------------------------------------
+// jax.random.choice(key, n, (bs,), replace=True, p): r = cum[-1] * (1 - uniform(key)),
+// index = searchsorted(cum, r) (left).
+__global__ void k_draw_prioritized(az_replay r, uint32_t k0, uint32_t k1, int bs,
+                                   int32_t* __restrict__ out_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs) return;
+  const float u = az_uniform_from_bits(az_random_bits32(k0, k1, (uint32_t)i), 0.0f, 1.0f);
+  const float target = r.cum[r.cap - 1] * (1.0f - u);
+  int lo = 0, hi = r.cap;  // first index with cum[index] >= target
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (r.cum[mid] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  out_idx[i] = lo;
+}
+
+// jax.random.randint(key, (bs,), minval, maxval), int32
+__global__ void k_draw_uniform(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, int bs,
+                               int minval, int maxval, int32_t* __restrict__ out_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs) return;
+  const uint32_t hi = az_random_bits32(a0, a1, (uint32_t)i), lo = az_random_bits32(b0, b1, (uint32_t)i);
+  const uint32_t span = maxval > minval ? (uint32_t)(maxval - minval) : 1u;
+  const uint32_t m = 65536u % span;
+  const uint32_t mult = (m * m) % span;
+  uint32_t off = (hi % span) * mult + (lo % span);
+  off = off % span;
+  out_idx[i] = minval + (int32_t)off;
+}
+
+// one workgroup of 64 threads per sampled row; indices wrap like jnp.take(mode='wrap')
+__global__ void k_replay_gather(az_replay r, int head, const int32_t* __restrict__ idx,
+                                float* __restrict__ out) {
+  int logical = idx[blockIdx.x] % r.cap;
+  if (logical < 0) logical += r.cap;
+  const int p = az_phys(logical, head, r.cap);
+  const float* src = r.rows + (size_t)p * r.D;
+  float* dst = out + (size_t)blockIdx.x * r.D;
+  for (int c = threadIdx.x; c < r.D - 2; c += blockDim.x) dst[c] = src[c];
+  if (threadIdx.x == 0) {
+    dst[r.D - 2] = r.priority[p];
+    dst[r.D - 1] = r.weight[p];
+  }
+}
+
+extern "C" int az_replay_sample_prioritized(const az_replay* r, const az_replay_state* st,
+                                            const uint32_t sample_key[2], float beta, int32_t bs,
+                                            int32_t* out_idx, float* out_batch, void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!sample_key || bs < 1 || !out_idx || !out_batch)
+    return az_fail(AZ_ERR_INVALID, "bad sample arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = az_scan_chunks(r->cap);
+  float* total = r->partial + 2 * nc;  // sum of the masked priorities
+  unsigned int* wmax = reinterpret_cast<unsigned int*>(r->partial + 2 * nc + 1);
+  // probs /= sum(probs): the sum is the last element of the (unnormalised) prefix sums
+  if (int rc = az_scan_launch(r, st, nullptr, 0, 0.0f, nullptr, false, s)) return rc;
+  k_scan_last<<<dim3(1), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, nullptr,
+                                                  r->partial + nc, total);
+  AZ_LAUNCH_CHECK();
+  AZ_HIP(hipMemsetAsync(wmax, 0, sizeof(unsigned int), s));
+  if (int rc = az_scan_launch(r, st, total, 1, beta, wmax, true, s)) return rc;
+  k_weights_normalise<<<dim3(1024), dim3(256), 0, s>>>(*r, wmax);
+  AZ_LAUNCH_CHECK();
+  k_draw_prioritized<<<dim3((bs + 255) / 256), dim3(256), 0, s>>>(*r, sample_key[0], sample_key[1],
+                                                                   bs, out_idx);
+  AZ_LAUNCH_CHECK();
+  k_replay_gather<<<dim3(bs), dim3(64), 0, s>>>(*r, st->head, out_idx, out_batch);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+extern "C" int az_replay_sample_uniform(const az_replay* r, const az_replay_state* st,
+                                        const uint32_t sample_key[2], int32_t bs, int32_t* out_idx,
+                                        float* out_batch, void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!sample_key || bs < 1 || !out_idx || !out_batch)
+    return az_fail(AZ_ERR_INVALID, "bad sample arguments");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t a0, a1, b0, b1;  // randint splits its key once more
+  az_key_split(sample_key[0], sample_key[1], 0u, &a0, &a1);
+  az_key_split(sample_key[0], sample_key[1], 1u, &b0, &b1);
+  k_draw_uniform<<<dim3((bs + 255) / 256), dim3(256), 0, s>>>(a0, a1, b0, b1, bs, st->sample_position,
+                                                              st->insert_position, out_idx);
+  AZ_LAUNCH_CHECK();
+  k_replay_gather<<<dim3(bs), dim3(64), 0, s>>>(*r, st->head, out_idx, out_batch);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// set_priorities with a defined winner for repeated indices: the highest batch position.
+__global__ void k_prio_claim(az_replay r, int head, const int32_t* __restrict__ idx, int bs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs) return;
+  int logical = idx[i] % r.cap;
+  if (logical < 0) logical += r.cap;
+  atomicMax(&r.owner[az_phys(logical, head, r.cap)], i);
+}
+__global__ void k_prio_write(az_replay r, int head, const int32_t* __restrict__ idx,
+                             const float* __restrict__ pri, int bs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs) return;
+  int logical = idx[i] % r.cap;
+  if (logical < 0) logical += r.cap;
+  const int p = az_phys(logical, head, r.cap);
+  if (r.owner[p] == i) r.priority[p] = pri[i];
+}
+__global__ void k_prio_release(az_replay r, int head, const int32_t* __restrict__ idx, int bs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs) return;
+  int logical = idx[i] % r.cap;
+  if (logical < 0) logical += r.cap;
+  r.owner[az_phys(logical, head, r.cap)] = -1;
+}
+
+extern "C" int az_replay_set_priorities(const az_replay* r, const az_replay_state* st,
+                                        const int32_t* idx, const float* priorities, int32_t bs,
+                                        void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!idx || !priorities || bs < 1) return az_fail(AZ_ERR_INVALID, "bad set_priorities arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g((bs + 255) / 256), b(256);
+  k_prio_claim<<<g, b, 0, s>>>(*r, st->head, idx, bs);
+  AZ_LAUNCH_CHECK();
+  k_prio_write<<<g, b, 0, s>>>(*r, st->head, idx, priorities, bs);
+  AZ_LAUNCH_CHECK();
+  k_prio_release<<<g, b, 0, s>>>(*r, st->head, idx, bs);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_replay_export(az_replay r, int head, float* __restrict__ out) {
+  const int logical = blockIdx.x;
+  const int p = az_phys(logical, head, r.cap);
+  const float* src = r.rows + (size_t)p * r.D;
+  float* dst = out + (size_t)logical * r.D;
+  for (int c = threadIdx.x; c < r.D - 2; c += blockDim.x) dst[c] = src[c];
+  if (threadIdx.x == 0) {
+    dst[r.D - 2] = r.priority[p];
+    dst[r.D - 1] = r.weight[p];
+  }
+}
+
+extern "C" int az_replay_export(const az_replay* r, const az_replay_state* st, float* out,
+                                void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!out) return az_fail(AZ_ERR_INVALID, "null export buffer");
+  k_replay_export<<<dim3(r->cap), dim3(64), 0, (hipStream_t)stream>>>(*r, st->head, out);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
+__global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int az_replay_scan(const az_replay* r, const az_replay_state* st, float* out_cum,
+                              float* out_total, void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!out_cum || !out_total) return az_fail(AZ_ERR_INVALID, "null scan outputs");
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = az_scan_chunks(r->cap);
+  if (int rc = az_scan_launch(r, st, nullptr, 0, 0.0f, nullptr, true, s)) return rc;
+  k_scan_last<<<dim3(1), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, nullptr,
+                                                  r->partial + nc, out_total);
+  AZ_LAUNCH_CHECK();
+  k_copy_f32<<<dim3(256), dim3(256), 0, s>>>(r->cum, out_cum, r->cap);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}

@@ -327,6 +327,27 @@ def math_apply(fn, x):
     return y
 
 
+def powf(x, e):
+    x = _f32(x)
+    y = np.zeros_like(x)
+    lib().oz_powf(C.c_int(x.size), _p(x), C.c_float(float(e)), _p(y))
+    return y
+
+
+def random_bits(key, n):
+    key = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(n, np.uint32)
+    lib().oz_random_bits(_p(key), C.c_int(n), _p(out))
+    return out
+
+
+def uniform01(key, n):
+    key = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(n, np.float32)
+    lib().oz_uniform01(_p(key), C.c_int(n), _p(out))
+    return out
+
+
 def threefry(key, ctr):
     key = np.ascontiguousarray(key, np.uint32).reshape(-1, 2)
     ctr = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 2)

@@ -1048,6 +1048,20 @@ void oz_math_apply(int fn, int n, const float* x, float* y) {
   }
 }
 
+/* x[i]^e with the shared pow (the replay sampler's importance weights). */
+void oz_powf(int n, const float* x, float e, float* y) {
+  for (int i = 0; i < n; ++i) y[i] = az_powf(x[i], e);
+}
+
+/* jax.random.bits(key, (n,), uint32) and jax.random.uniform(key, (n,)) in [0, 1). */
+void oz_random_bits(const uint32_t* key, int n, uint32_t* out) {
+  for (int i = 0; i < n; ++i) out[i] = az_random_bits32(key[0], key[1], (uint32_t)i);
+}
+void oz_uniform01(const uint32_t* key, int n, float* out) {
+  for (int i = 0; i < n; ++i)
+    out[i] = az_uniform_from_bits(az_random_bits32(key[0], key[1], (uint32_t)i), 0.0f, 1.0f);
+}
+
 void oz_threefry(int n, const uint32_t* key, const uint32_t* ctr, uint32_t* out) {
   for (int i = 0; i < n; ++i)
     az_threefry2x32(key[2 * i], key[2 * i + 1], ctr[2 * i], ctr[2 * i + 1], &out[2 * i],

@@ -20,8 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    header = open(os.path.join(ROOT, "include", "az_mcts.h")).read()
-    declared = set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", header))
+    declared = set()
+    for h in ("az_mcts.h", "az_replay.h"):
+        header = open(os.path.join(ROOT, "include", h)).read()
+        header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)   # comments mention other names
+        declared |= set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", header))
     assert declared, "no declarations found"
     lib = nat.lib()
     for name in sorted(declared):
@@ -38,6 +41,9 @@ def test_struct_layouts_match_header():
     assert C.sizeof(nat.Injected) == 4 * 8
     assert C.sizeof(nat.MlpParams) == 4 + 9 * 4 + 8 * 8 * 2
     assert C.sizeof(nat.Model) == 7 * 4 + 2 * 9 * 4 + 4 + 3 * 8  # 4 bytes padding before pointers
+    # include/az_replay.h
+    assert C.sizeof(nat.Replay) == 6 * 8 + 2 * 4
+    assert C.sizeof(nat.ReplayState) == 3 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):
