@@ -1,0 +1,230 @@
+"""The training step of the reference's driver, one process per GPU.
+
+Mirrors alphazero.py: `actor_step` (:287-403), `generate_unroll` (:406-430), `training_step`
+(:1092-1183), `prefill_replay_buffer` (:1224-1296) and the evaluator's episode loop
+(:433-508) for the built-in environments.  Self-play (search, environment, networks in
+the tree) runs in the HIP kernels; the learner side is `learner.py`; replay is
+`replay_buffers.py`.  Data parallelism follows alphazero.py:893-896, 935-943: every rank
+owns `num_envs // world` lanes, its share of the replay rows and of the sampled batch;
+the only collectives are the gradient mean per minibatch and the observation-statistics
+sums per training step (torch.distributed: RCCL on GPUs).
+"""
+import dataclasses
+import time
+
+import torch
+
+from . import envs as envs_lib
+from . import learner as L
+from . import networks, parallel, policies, prng, replay_buffers
+from .base import RootFnOutput
+from .qtransforms import qtransform_by_parent_and_siblings, qtransform_completed_by_mix_value
+
+
+@dataclasses.dataclass
+class Config:
+    """The hyper-parameters of alphazero.py:37-100 that the training step reads."""
+    env_id: str = "CartPole-v1"
+    seed: int = 0
+    num_envs: int = 64
+    episode_length: int = 500
+    unroll_length: int = 8
+    num_simulations: int = 32
+    policy: str = "sampled"            # "sampled" (alphazero.py:354), "muzero", "gumbel"
+    num_samples: int = 16
+    max_num_considered_actions: int = 16
+    policy_hidden: tuple = (32, 32, 32, 32)
+    value_hidden: tuple = (256, 256, 256, 256, 256)
+    num_atoms: int = 1
+    qr_kappa: float = 1.0
+    use_gae: bool = False
+    gae_lambda: float = 0.95
+    n_step_n: int = 5
+    n_step_gamma: float = 0.99
+    max_replay_size: int = 1 << 16
+    min_replay_size: int = 0
+    replay_buffer_batch_size: int = 128
+    num_minibatches: int = 4
+    update_epochs: int = 1
+    per_alpha: float = 0.0
+    per_importance_sampling: bool = True
+    per_importance_sampling_beta: float = 1.0
+    learning_rate: float = 1e-3
+    anneal_lr: bool = True
+    total_timesteps: int = 1_000_000
+    max_grad_norm: float = 0.5
+    vf_cost: float = 0.5
+    l2_coef: float = 1e-4
+    normalize_observations: bool = True
+
+
+class Trainer:
+    def __init__(self, cfg, device=None):
+        self.cfg = cfg
+        self.rank, self.world, local = parallel.env_rank()
+        self.device = torch.device("cuda", local) if device is None else torch.device(device)
+        shard = parallel.shard_lanes(cfg.num_envs, self.rank, self.world, key=cfg.seed)
+        self.lanes = shard.lanes
+        self.key = shard.key
+        self.env = envs_lib.make(cfg.env_id, episode_length=cfg.episode_length)
+        obs, act = envs_lib.observation_size(cfg.env_id), envs_lib.action_size(cfg.env_id)
+        # identical initial parameters on every rank (alphazero.py:1305-1326 replicates them)
+        g = torch.Generator(device=self.device).manual_seed(cfg.seed)
+        self.policy_layers = networks.init_mlp((obs,) + tuple(cfg.policy_hidden) + (act,), g, self.device)
+        self.value_layers = networks.init_mlp((obs,) + tuple(cfg.value_hidden) + (cfg.num_atoms,), g,
+                                              self.device)
+        self.stats = L.RunningStatistics(obs, device=self.device)
+        self.model = networks.FusedModel(cfg.env_id, self.policy_layers, self.value_layers,
+                                         self.stats.mean, self.stats.std, gamma=cfg.n_step_gamma)
+        self.recurrent_fn = networks.FusedRecurrentFn(self.model)
+        self.optimizer = L.ClipAdam(L.flat_leaves(self.policy_layers, self.value_layers),
+                                    cfg.learning_rate, cfg.max_grad_norm, cfg.anneal_lr,
+                                    cfg.total_timesteps)
+        self.layout = L.row_layout(obs, act, cfg.num_atoms)
+        sample_bs = cfg.replay_buffer_batch_size * cfg.num_minibatches // self.world
+        cap = cfg.max_replay_size // self.world
+        if cfg.per_alpha > -1:                                        # alphazero.py:933-943
+            self.replay = replay_buffers.PrioritizedSamplingQueue(
+                cap, self.layout["_width"], sample_bs, cfg.per_importance_sampling_beta)
+        else:
+            self.replay = replay_buffers.UniformSamplingQueue(cap, self.layout["_width"], sample_bs)
+        self.key, kb, ke = prng.split(self.key, 3)
+        self.buffer_state = self.replay.init(kb, device=self.device)
+        self.env_state = self.env.reset(ke, batch_size=self.lanes, device=self.device)
+        self.env_steps = 0
+        self._perm_gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1)
+
+    # -------------------------------------------------------------- self-play
+    def _refresh_model(self):
+        mean, std = (self.stats.mean, self.stats.std) if self.cfg.normalize_observations else (None, None)
+        self.model.update(self.policy_layers, self.value_layers, mean, std)
+
+    def actor_step(self, key, deterministic=False):
+        """alphazero.py:287-403: search on the current states, act, step the environment."""
+        cfg, st = self.cfg, self.env_state
+        logits, value = self.model.forward(st.obs)
+        root = RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
+        if cfg.policy == "gumbel":
+            out = policies.gumbel_muzero_policy(
+                (), key, root, self.recurrent_fn, cfg.num_simulations,
+                max_num_considered_actions=cfg.max_num_considered_actions,
+                qtransform=qtransform_completed_by_mix_value)
+        elif cfg.policy == "muzero":
+            out = policies.muzero_policy((), key, root, self.recurrent_fn, cfg.num_simulations,
+                                         qtransform=qtransform_by_parent_and_siblings)
+        else:
+            out = policies.sampled_muzero_policy((), key, root, self.recurrent_fn,
+                                                 cfg.num_simulations, num_samples=cfg.num_samples)
+        action, search_value, log_prob = policies.actor_post(
+            out.search_tree, out.action_weights, out.action, logits, deterministic=deterministic)
+        obs, real_obs = st.obs.clone(), st.real_obs.clone()
+        nst = self.env.step(st, action)
+        ones = torch.ones_like(nst.reward)
+        tr = dict(observation=obs, real_obs=real_obs, action=action.float(), reward=nst.reward,
+                  discount=1 - nst.done, next_observation=nst.real_obs,
+                  target_policy_probs=out.action_weights, search_value=search_value,
+                  value_prefix_target=torch.zeros_like(nst.reward),
+                  bootstrap_observation=torch.zeros_like(obs),
+                  bootstrap_value=value,            # overloaded with the prior value (:396)
+                  bootstrap_discount=ones, prior_log_prob=log_prob, raw_action=action.float(),
+                  truncation=nst.truncation, priority=ones, weight=ones)
+        return nst, tr
+
+    def generate_unroll(self, key, length):
+        """alphazero.py:406-430: dict of [T, B, ...] tensors."""
+        steps = []
+        for _ in range(length):
+            key, sub = prng.split(key, 2)[1], prng.split(key, 2)[0]
+            self.env_state, tr = self.actor_step(sub)
+            steps.append(tr)
+        return {k: torch.stack([s[k] for s in steps], 0) for k in steps[0]}
+
+    def _targets(self, data, final_search_value):
+        cfg = self.cfg
+        trunc = data["truncation"]
+        kw = dict(rewards=data["reward"], discounts=data["discount"] * (1 - trunc),
+                  termination_discount=data["discount"], observations=data["next_observation"],
+                  values=torch.cat([data["search_value"], final_search_value.unsqueeze(0)], 0))
+        if cfg.use_gae:
+            return L.compute_gae(**kw, lambda_=cfg.gae_lambda, discount=cfg.n_step_gamma)
+        return L.n_step_bootstrapped_targets(**kw, n=cfg.n_step_n, gamma=cfg.n_step_gamma)
+
+    def collect(self, key):
+        """alphazero.py:1104-1151: unroll, bootstrap search, targets, priorities, insert."""
+        cfg = self.cfg
+        k_unroll, k_boot = prng.split(key, 2)
+        data = self.generate_unroll(k_unroll, cfg.unroll_length)
+        saved = self.env_state
+        _, boot = self.actor_step(k_boot)       # the extra search only provides the bootstrap value
+        self.env_state = saved
+        prefix, b_obs, b_val, b_disc = self._targets(data, boot["search_value"])
+        targets = prefix.unsqueeze(-1) + b_disc.unsqueeze(-1) * b_val
+        data["priority"] = L.priorities(targets, data["bootstrap_value"], cfg.per_alpha)
+        data.update(value_prefix_target=prefix, bootstrap_observation=b_obs, bootstrap_value=b_val,
+                    bootstrap_discount=b_disc)
+        flat = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in data.items()}
+        rows = L.pack_rows(self.layout, flat)
+        self.replay.insert(self.buffer_state, rows)
+        self.env_steps += cfg.unroll_length * self.lanes * self.world
+        return flat
+
+    # -------------------------------------------------------------- training
+    def training_step(self):
+        """alphazero.py:1092-1183."""
+        cfg = self.cfg
+        self.key, k_collect = prng.split(self.key, 2)
+        flat = self.collect(k_collect)
+        if cfg.normalize_observations:
+            self.stats.update(flat["observation"])
+        mean, std = self.stats.mean, self.stats.std
+        self.buffer_state, rows = self.replay.sample(self.buffer_state)
+        batch = L.unpack_rows(self.layout, rows)
+        metrics = []
+        for _ in range(cfg.update_epochs):
+            metrics += L.sgd_step(self.policy_layers, self.value_layers, mean, std, batch,
+                                  self.optimizer, cfg.num_atoms, cfg.num_minibatches,
+                                  generator=self._perm_gen, qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost,
+                                  l2_coef=cfg.l2_coef,
+                                  per_importance_sampling=cfg.per_importance_sampling)
+        # refresh the priorities of the sampled rows with the PRE-update networks (:1177-1180)
+        targets = batch["value_prefix_target"].unsqueeze(-1) + \
+            batch["bootstrap_discount"].unsqueeze(-1) * batch["bootstrap_value"]
+        _, values = self.model.forward(batch["observation"].contiguous())
+        self.replay.set_priorities(self.buffer_state, L.priorities(targets, values, cfg.per_alpha))
+        self._refresh_model()
+        out = {k: torch.stack([m[k] for m in metrics]).mean() for k in metrics[0]}
+        out["buffer_current_size"] = self.replay.size(self.buffer_state)
+        return out
+
+    def prefill(self):
+        """alphazero.py:1224-1296: collect without learning until min_replay_size rows."""
+        while self.replay.size(self.buffer_state) * self.world < self.cfg.min_replay_size:
+            self.key, k = prng.split(self.key, 2)
+            self.collect(k)
+
+    def evaluate(self, num_steps):
+        """alphazero.py:433-508 in short: greedy actions, mean reward per step and the number
+        of finished episodes over `num_steps` actor steps."""
+        saved = self.env_state
+        key, reward, episodes = prng.split(self.key, 2)[1], 0.0, 0.0
+        for _ in range(num_steps):
+            key, sub = prng.split(key, 2)
+            self.env_state, tr = self.actor_step(sub, deterministic=True)
+            reward += float(tr["reward"].mean())
+            episodes += float((1 - tr["discount"]).sum())
+        self.env_state = saved
+        return dict(mean_reward=reward / num_steps, episodes=episodes)
+
+    def train(self, num_training_steps, log=None):
+        t0 = time.perf_counter()
+        steps0 = self.env_steps
+        m = {}
+        for _ in range(num_training_steps):
+            m = self.training_step()
+        torch.cuda.synchronize(self.device)
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, device=self.device)
+        m = {k: float(v) for k, v in m.items()}
+        m["training/sps"] = (self.env_steps - steps0) / dt          # alphazero.py:1210-1212
+        if log:
+            log(m)
+        return m

@@ -1,0 +1,258 @@
+"""Learner-side formulas (alphazero_amd/learner.py, PyTorch) against the NumPy restatement
+of alphazero.py (oracle/learner_numpy.py).  The CPU tests run in float64, where both sides
+must agree to 1e-10; the GPU test runs the float32 path and allows 1e-5 relative."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from alphazero_amd import learner as L
+from oracle import learner_numpy as O
+
+
+def seq_inputs(rng, T=9, B=5, K=3, obs=4, dtype=np.float64):
+    done = (rng.random((T, B)) < 0.2).astype(dtype)
+    trunc = (rng.random((T, B)) < 0.1).astype(dtype) * (1 - done)
+    disc = 1 - done
+    return dict(rewards=rng.standard_normal((T, B)).astype(dtype), discounts=disc * (1 - trunc),
+                termination_discount=disc, observations=rng.standard_normal((T, B, obs)).astype(dtype),
+                values=rng.standard_normal((T + 1, B, K)).astype(dtype))
+
+
+def to_t(d, device="cpu"):
+    return {k: torch.as_tensor(v, device=device) for k, v in d.items()}
+
+
+def close(a, b, tol):
+    np.testing.assert_allclose(a.detach().cpu().numpy() if hasattr(a, "detach") else a, b,
+                               rtol=tol, atol=tol)
+
+
+def check_targets(device, dtype, tol):
+    rng = np.random.default_rng(0)
+    for T, n in ((9, 5), (3, 5), (6, 1), (8, 2)):
+        x = seq_inputs(rng, T=T, dtype=dtype)
+        ref = O.n_step_bootstrapped_targets(**x, n=n, gamma=0.99)
+        out = L.n_step_bootstrapped_targets(**to_t(x, device), n=n, gamma=0.99)
+        for a, b in zip(out, ref):
+            close(a, b, tol)
+        ref = O.compute_gae(**x, lambda_=0.95, discount=0.99)
+        out = L.compute_gae(**to_t(x, device), lambda_=0.95, discount=0.99)
+        for a, b in zip(out, ref):
+            close(a, b, tol)
+    t = rng.standard_normal((7, 3)).astype(dtype)
+    v = rng.standard_normal((7, 3)).astype(dtype)
+    for alpha in (0.0, 0.6, 1.0):
+        close(L.priorities(torch.as_tensor(t, device=device), torch.as_tensor(v, device=device), alpha),
+              O.priorities(t, v, alpha), tol)
+
+
+def make_model(rng, obs=4, A=3, K=1, dtype=np.float64):
+    def net(sizes):
+        return [((rng.standard_normal((i, o)) / np.sqrt(i)).astype(dtype), (rng.standard_normal(o) * 0.1).astype(dtype))
+                for i, o in zip(sizes[:-1], sizes[1:])]
+    return net((obs, 8, 8, A)), net((obs, 16, 16, K))
+
+
+def make_batch(rng, N=32, obs=4, A=3, K=1, dtype=np.float64):
+    p = rng.random((N, A)).astype(dtype)
+    return dict(observation=rng.standard_normal((N, obs)).astype(dtype),
+                target_policy_probs=p / p.sum(-1, keepdims=True),
+                value_prefix_target=rng.standard_normal(N).astype(dtype),
+                bootstrap_discount=rng.random(N).astype(dtype),
+                bootstrap_value=rng.standard_normal((N, K)).astype(dtype),
+                weight=rng.random(N).astype(dtype), raw_action=rng.integers(0, A, N).astype(dtype),
+                prior_log_prob=-rng.random(N).astype(dtype))
+
+
+def check_loss(device, dtype, tol, K):
+    rng = np.random.default_rng(K)
+    pol, val = make_model(rng, K=K, dtype=dtype)
+    batch = make_batch(rng, K=K, dtype=dtype)
+    mean, std = rng.standard_normal(4).astype(dtype) * 0.1, (rng.random(4) + 0.5).astype(dtype)
+    ref, rm = O.muzero_loss(pol, val, mean, std, batch, K)
+    tp = [(torch.as_tensor(w, device=device), torch.as_tensor(b, device=device)) for w, b in pol]
+    tv = [(torch.as_tensor(w, device=device), torch.as_tensor(b, device=device)) for w, b in val]
+    out, m = L.compute_muzero_loss(tp, tv, torch.as_tensor(mean, device=device),
+                                   torch.as_tensor(std, device=device), to_t(batch, device), K)
+    close(out, ref, tol)
+    for k in rm:
+        close(m[k], rm[k], tol)
+    return pol, val, mean, std, batch, tp, tv
+
+
+def test_targets_and_priorities_float64():
+    check_targets("cpu", np.float64, 1e-12)
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_loss_and_gradient_float64(K):
+    pol, val, mean, std, batch, tp, tv = check_loss("cpu", np.float64, 1e-10, K)
+    leaves = L.flat_leaves(tp, tv)
+    for p in leaves:
+        p.requires_grad_(True)
+    total, _ = L.compute_muzero_loss(tp, tv, torch.as_tensor(mean), torch.as_tensor(std), to_t(batch), K)
+    grads = torch.autograd.grad(total, leaves)
+    # central differences of the NumPy loss on a few coordinates of every leaf
+    rng = np.random.default_rng(1)
+    arrays = [a for w, b in pol + val for a in (w, b)]
+    for li, arr in enumerate(arrays):
+        for _ in range(3):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            old = arr[idx]
+            arr[idx] = old + 1e-6
+            up, _ = O.muzero_loss(pol, val, mean, std, batch, K)
+            arr[idx] = old - 1e-6
+            dn, _ = O.muzero_loss(pol, val, mean, std, batch, K)
+            arr[idx] = old
+            np.testing.assert_allclose(grads[li][idx].item(), (up - dn) / 2e-6, rtol=1e-5, atol=1e-8)
+
+
+def test_quantile_loss_shapes_and_symmetry():
+    v = torch.zeros(2, 4, dtype=torch.float64)
+    t = torch.zeros(2, 4, dtype=torch.float64)
+    assert L.quantile_regression_loss(v, t, 1.0, 4).abs().max() == 0
+    rng = np.random.default_rng(2)
+    a, b = rng.standard_normal((5, 4)), rng.standard_normal((5, 4))
+    close(L.quantile_regression_loss(torch.as_tensor(a), torch.as_tensor(b), 1.0, 4),
+          O.quantile_regression_loss(a, b, 1.0, 4), 1e-12)
+
+
+def test_clip_adam_and_schedule_vs_oracle():
+    rng = np.random.default_rng(3)
+    params = [rng.standard_normal(s) for s in ((4, 8), (8,), (8, 2), (2,))]
+    tparams = [torch.as_tensor(p.copy()) for p in params]
+    opt = L.ClipAdam(tparams, learning_rate=1e-3, max_grad_norm=0.5, anneal_lr=True, total_timesteps=10)
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    for step in range(14):
+        scale = 10.0 if step % 2 else 0.01      # above and below the clipping norm
+        grads = [rng.standard_normal(p.shape) * scale for p in params]
+        lr = O.linear_schedule(1e-3, 1e-5, 10, step)
+        assert abs(opt.learning_rate() - lr) < 1e-15
+        params, m, v = O.clip_adam_step(params, grads, m, v, step, lr, 0.5)
+        opt.step([torch.as_tensor(g) for g in grads])
+        for a, b in zip(tparams, params):
+            close(a, b, 1e-12)
+
+
+def test_running_statistics_vs_oracle():
+    rng = np.random.default_rng(4)
+    rs = L.RunningStatistics(4, dtype=torch.float64)
+    c, mean, sv = 0, np.zeros(4), np.zeros(4)
+    for _ in range(3):
+        b = rng.standard_normal((6, 5, 4)) * 3 + 1
+        c, mean, sv, std = O.running_statistics_update(c, mean, sv, [b])
+        rs.update(torch.as_tensor(b))
+        assert rs.count == c
+        close(rs.mean, mean, 1e-12)
+        close(rs.std, std, 1e-12)
+    np.testing.assert_allclose(rs.std.numpy(), 3.0, rtol=0.2)
+
+
+def test_row_layout_round_trip():
+    lay = L.row_layout(4, 2, 1)
+    assert lay["_width"] == 4 * 4 + 2 + 2 * 1 + 10 and lay["priority"][0] == lay["_width"] - 2
+    rng = np.random.default_rng(5)
+    f = {k: torch.as_tensor(rng.standard_normal((7, lay[k][1])).astype(np.float32))
+         for k in lay if k != "_width"}
+    rows = L.pack_rows(lay, f)
+    back = L.unpack_rows(lay, rows)
+    for k in f:
+        assert torch.equal(back[k].reshape(7, -1), f[k])
+
+
+# ---- two ranks: the averaged gradient equals the gradient of the concatenated batch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        pol, val = make_model(rng)
+        batch = make_batch(rng, N=32)
+        tp = [(torch.as_tensor(w.copy()), torch.as_tensor(b.copy())) for w, b in pol]
+        tv = [(torch.as_tensor(w.copy()), torch.as_tensor(b.copy())) for w, b in val]
+        half = {k: torch.as_tensor(v[rank * 16:(rank + 1) * 16]) for k, v in batch.items()}
+        opt = L.ClipAdam(L.flat_leaves(tp, tv), anneal_lr=False)
+        L.minibatch_step(tp, tv, torch.zeros(4, dtype=torch.float64), torch.ones(4, dtype=torch.float64),
+                         half, opt, 1, per_importance_sampling=False)
+        rs = L.RunningStatistics(4, dtype=torch.float64)
+        rs.update(torch.as_tensor(batch["observation"][rank * 16:(rank + 1) * 16]))
+        out.put((rank, [p.numpy().copy() for p in L.flat_leaves(tp, tv)], rs.count,
+                 rs.mean.numpy().copy(), rs.std.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_and_statistics_allreduce():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process on the whole batch (policy and unweighted value losses are means, so the
+    # mean of the two half-batch gradients is the full-batch gradient)
+    rng = np.random.default_rng(7)
+    pol, val = make_model(rng)
+    batch = make_batch(rng, N=32)
+    tp = [(torch.as_tensor(w.copy()), torch.as_tensor(b.copy())) for w, b in pol]
+    tv = [(torch.as_tensor(w.copy()), torch.as_tensor(b.copy())) for w, b in val]
+    opt = L.ClipAdam(L.flat_leaves(tp, tv), anneal_lr=False)
+    L.minibatch_step(tp, tv, torch.zeros(4, dtype=torch.float64), torch.ones(4, dtype=torch.float64),
+                     to_t(batch), opt, 1, per_importance_sampling=False)
+    for r in res:
+        for a, b in zip(r[1], L.flat_leaves(tp, tv)):
+            np.testing.assert_allclose(a, b.numpy(), rtol=1e-9, atol=1e-12)
+    c, mean, sv, std = O.running_statistics_update(0, np.zeros(4), np.zeros(4),
+                                                   [batch["observation"][:16], batch["observation"][16:]])
+    for r in res:
+        assert r[2] == c
+        np.testing.assert_allclose(r[3], mean, rtol=1e-12)
+        np.testing.assert_allclose(r[4], std, rtol=1e-12)
+
+
+# ---- the float32 path on the GPU
+@pytest.mark.gpu
+def test_float32_gpu_vs_float64_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rng = np.random.default_rng(0)
+    x = seq_inputs(rng, T=32, B=64, K=1, dtype=np.float32)
+    x64 = {k: v.astype(np.float64) for k, v in x.items()}
+    for fn, kw in ((("n_step_bootstrapped_targets"), dict(n=5, gamma=0.99)),
+                   (("compute_gae"), dict(lambda_=0.95, discount=0.99))):
+        ref = getattr(O, fn)(**x64, **kw)
+        out = getattr(L, fn)(**to_t(x, "cuda"), **kw)
+        for a, b in zip(out, ref):
+            close(a, b, 1e-5)
+    for K in (1, 8):
+        rng = np.random.default_rng(10 + K)
+        pol, val = make_model(rng, K=K, dtype=np.float32)
+        batch = make_batch(rng, N=512, K=K, dtype=np.float32)
+        to64 = lambda net: [(w.astype(np.float64), b.astype(np.float64)) for w, b in net]  # noqa: E731
+        ref, rm = O.muzero_loss(to64(pol), to64(val), np.zeros(4), np.ones(4),
+                                {k: v.astype(np.float64) for k, v in batch.items()}, K)
+        tp = [(torch.as_tensor(w).cuda(), torch.as_tensor(b).cuda()) for w, b in pol]
+        tv = [(torch.as_tensor(w).cuda(), torch.as_tensor(b).cuda()) for w, b in val]
+        out, m = L.compute_muzero_loss(tp, tv, torch.zeros(4).cuda(), torch.ones(4).cuda(),
+                                       to_t(batch, "cuda"), K)
+        close(out, ref, 1e-5)
+        for k in rm:
+            close(m[k], rm[k], 1e-5)
