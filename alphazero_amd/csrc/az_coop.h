@@ -30,8 +30,11 @@
 #define AZ_TREE_THREADS (AZ_GROUP * AZ_WG_LANES)
 
 // Words of LDS per lane: sel[N], edge_r[N], edge_d[N], path[S+1], pr[S], pd[S], hdr[8],
-// root_g[8], root_inv[8], root_tab[S].
-__host__ __device__ inline int az_coop_lane_words(int S) { return 7 * S + 28; }
+// root_g[8], root_inv[8], root_tab[S].  With `borrowed`, pr and pd live in memory the
+// caller lends (2*S floats per lane, free between evaluations) and are not counted.
+__host__ __device__ inline int az_coop_lane_words(int S, bool borrowed = false) {
+  return (borrowed ? 5 : 7) * S + 28;
+}
 
 struct CoopLds {
   int32_t* sel;   // [N]   (action << 16) | (child + 1) currently selected at each node
@@ -44,17 +47,23 @@ struct CoopLds {
   float* root_g;      // [8] the root's Gumbel noise
   float* root_inv;    // [8] the root's invalid-action mask
   int32_t* root_tab;  // [S] the row of the considered-visits table this lane uses
-  AZ_DEV CoopLds(float* base, int lane, int S) {
-    float* p = base + (size_t)lane * az_coop_lane_words(S);
+  AZ_DEV CoopLds(float* base, int lane, int S, float* borrowed = nullptr) {
+    float* p = base + (size_t)lane * az_coop_lane_words(S, borrowed != nullptr);
     const int N = S + 1;
     sel = reinterpret_cast<int32_t*>(p);
     edge_r = p + N;
     edge_d = p + 2 * N;
     path = reinterpret_cast<int32_t*>(p + 3 * N);
-    pr = p + 4 * N;
-    pd = p + 4 * N + S;
-    hdr = reinterpret_cast<int32_t*>(p + 4 * N + 2 * S);
-    root_g = p + 4 * N + 2 * S + 8;
+    float* q = p + 4 * N;
+    if (borrowed) {
+      pr = borrowed + (size_t)lane * 2 * S;
+    } else {
+      pr = q;
+      q += 2 * S;
+    }
+    pd = pr + S;
+    hdr = reinterpret_cast<int32_t*>(q);
+    root_g = q + 8;
     root_inv = root_g + 8;
     root_tab = reinterpret_cast<int32_t*>(root_inv + 8);
   }
@@ -210,11 +219,12 @@ AZ_DEV void az_coop_fill_edges(const CoopLds& s, int j, int dep) {
 }
 
 // Largest path depth over the workgroup's lanes (uniform across the workgroup).
-AZ_DEV int az_coop_max_depth(float* lds_base, int S) {
+AZ_DEV int az_coop_max_depth(float* lds_base, int S, bool borrowed = false) {
   int m = 0;
 #pragma unroll
   for (int i = 0; i < AZ_WG_LANES; ++i) {
-    const int d = CoopLds(lds_base, i, S).hdr[0];
+    const int d = reinterpret_cast<const int32_t*>(
+        lds_base + (size_t)i * az_coop_lane_words(S, borrowed) + 4 * (S + 1) + (borrowed ? 0 : 2 * S))[0];
     m = d > m ? d : m;
   }
   return m;

@@ -316,12 +316,15 @@ AZ_DEV int az_opaque(int v) {
 // (16 lanes x 32 threads) and all AZ_MLP_WAVES waves run the networks.
 template <int AMAX, int KMAX>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
-    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
+    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, int borrow, unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
   MlpLds s(lds, md.pol_kp, md.val_kp);
   float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp);
+  // `borrow`: the path's edge rewards / discounts are kept in the networks' activation
+  // buffers, which are free between two evaluations (needed when S is large)
+  float* lent = borrow ? s.pa : nullptr;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
   // beyond the path's depth do nothing and the 16 lane leaders (position 0) share wave 0
@@ -331,10 +334,10 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
   const bool leader = active && j == 0;
-  CoopLds cs(tree_lds, ln, S);
+  CoopLds cs(tree_lds, ln, S, lent);
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
-  float* emb = emb_in_lds ? tree_lds + AZ_WG_LANES * az_coop_lane_words(S) + ln * (S + 1) * 5 : nullptr;
+  float* emb = emb_in_lds ? tree_lds + AZ_WG_LANES * az_coop_lane_words(S, borrow != 0) + ln * (S + 1) * 5 : nullptr;
   az_stage_inputs(md, s, tid, blockDim.x);
   if (j == 0) {
     cs.hdr[0] = -1;
@@ -398,14 +401,18 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
       // the row loads before the networks run, so that their latency hides behind the MLPs.
       dep = cs.hdr[0];
       newn = cs.hdr[1];
-      if (active) az_coop_fill_edges(cs, j, dep);
+      if (active && !borrow) az_coop_fill_edges(cs, j, dep);
       if (kPrefetch && active && j <= dep) az_coop_load<AMAX, KMAX>(l, cs, j, dep, newn, P0);
     }
     az_forward_tile<AZ_MLP_WAVES, true, false>(md, s, wave, lane, regs);
     AZ_SIM_STAMP(4);
+    if (borrow) {  // the activation buffers are free now
+      if (active) az_coop_fill_edges(cs, j, dep);
+      __syncthreads();
+    }
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
-      const int maxdep = az_coop_max_depth(tree_lds, S);
+      const int maxdep = az_coop_max_depth(tree_lds, S, borrow != 0);
       const int parent = cs.hdr[2], action = cs.hdr[3];
       const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
       if (leader) {
@@ -456,8 +463,12 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
                    d->K, md.A, md.K);
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   SearchCtx c{*d, *in};
-  if (az_coop_applicable(d, lds)) {
-    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+  // borrowed storage for the path's edge values: only when the plain layout does not fit
+  // and the activation buffers are large enough (2 * S floats per lane)
+  const bool can_borrow = d->S <= az_act_stride(md.pol_kp) + az_act_stride(md.val_kp);
+  const int borrow = !az_coop_applicable(d, lds, false) && can_borrow && az_coop_applicable(d, lds, true);
+  if (borrow || az_coop_applicable(d, lds, false)) {
+    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrow != 0) * 4;
     const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
     const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
     if (emb_in_lds) lds2 += emb_bytes;
@@ -466,7 +477,7 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
         if (int rc = az_set_lds((const void*)k_search_fused_coop<AMAX, KMAX>, lds2)) return rc;
         k_search_fused_coop<AMAX, KMAX>
             <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
-               (hipStream_t)stream>>>(c, *t, md, emb_in_lds,
+               (hipStream_t)stream>>>(c, *t, md, emb_in_lds, borrow,
                                       reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;

@@ -10,7 +10,7 @@
 int az_fail(int code, const char* fmt, ...);
 int az_check_desc(const az_search_desc* d, const az_tree* t);
 int az_check_inputs(const az_search_desc* d, const az_search_inputs* in);
-bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes);
+bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool borrowed);
 
 #define AZ_HIP(call)                                                                 \
   do {                                                                               \

@@ -153,12 +153,12 @@ AZ_UNROLL_K
 // Whether the cooperative form applies (see az_coop.h) and fits in LDS next to
 // `extra_lds_bytes` of other use.  AZ_FORCE_LITERAL=1 in the environment selects the
 // literal kernels (used to cross-check the two forms).
-bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes) {
+bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool borrowed) {
   const char* force = getenv("AZ_FORCE_LITERAL");
   if (force && force[0] == '1') return false;
   if (!(d->variant == AZ_VARIANT_GUMBEL || d->noise_mode == AZ_NOISE_ZERO)) return false;
   if (d->A > 8 || d->K > 8 || d->S + 1 > 65535) return false;
-  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + extra_lds_bytes;
+  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrowed) * 4 + extra_lds_bytes;
   return bytes <= 160 * 1024;
 }
 
@@ -170,7 +170,7 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
   if (!inj || !inj->prior_logits || !inj->value || !inj->reward || !inj->discount)
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
-  if (az_coop_applicable(d, 0)) {
+  if (az_coop_applicable(d, 0, false)) {
     const size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
