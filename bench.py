@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--env", default="CartPole-v1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-lanes", type=int, default=0, help="lanes of the CPU baseline sample")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="all ranks share cuda:0 and reduce over gloo (checks the N > 1 code path "
+                        "on a one-GPU box; not a measurement)")
     return p.parse_args()
 
 
@@ -144,11 +147,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run "
                              "(--nproc-per-node must equal --gpus)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    red_device = torch.device("cpu") if args.rehearse_on_one_gpu else device
 
     def barrier():
         if world > 1:
@@ -169,8 +178,8 @@ def main():
         actor.step(stats)
         stats_list.append(stats)
     barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
-    total_sims = parallel.sum_over_ranks(B * S * args.steps, device=device)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=red_device)
+    total_sims = parallel.sum_over_ranks(B * S * args.steps, device=red_device)
 
     # dominant kernel: the fused persistent search, timed with HIP events on its stream
     ktimes = [s["events"][0][0].elapsed_time(s["events"][0][1]) * 1e-3 for s in stats_list]
