@@ -18,8 +18,15 @@
 // Every floating-point operation is the same, on the same operands and in the same
 // order, as in the literal form (az_device.h), so the resulting tree is bit-identical.
 //
-// Applicability: the selection must not depend on per-visit randomness (Gumbel
-// variant, or PUCT with the tie-break noise disabled), A <= 8, K <= 8, N <= 65535.
+// Per-visit randomness: the PUCT rules add 1e-7 * uniform noise to break ties.  A cached
+// pick is marked ambiguous when that noise could change it (the top two scores closer
+// than the noise), and the chase then evaluates that node exactly, with the visit's own
+// noise, as the literal form does; everywhere else the noise cannot matter.
+//
+// The kernels are instantiated twice (NOISY): the form without per-visit noise (Gumbel, or
+// PUCT with the noise disabled) carries none of that code.
+//
+// Applicability: A <= 8, K <= 8, N <= 65535.
 #ifndef AZ_COOP_H_
 #define AZ_COOP_H_
 
@@ -141,23 +148,80 @@ AZ_UNROLL_K
   r.node_visit = f.nv;
 }
 
-// The action the search's selection rule picks at a node (root: depth 0).
-template <int AMAX>
+// The action the search's selection rule picks at a node (root: depth 0), evaluated
+// WITHOUT per-visit noise.  `ambiguous` tells whether the PUCT tie-break noise
+// (1e-7 * u, u in [0, 1)) could change the pick: it cannot when the best score leads every
+// other one by more than the noise plus the rounding of the additions; otherwise the chase
+// re-evaluates the node with the visit's actual noise (az_coop_exact_select).
+template <int AMAX, bool NOISY>
 AZ_DEV int az_select_cached(const SearchCtx& c, const CoopLds& s, int A, int b, bool root,
-                            const NodeRow<AMAX>& r) {
+                            const NodeRow<AMAX>& r, bool& ambiguous) {
   const RootCache rc = s.root_cache(c);
+  ambiguous = false;
   if (c.d.variant == AZ_VARIANT_GUMBEL)
     return root ? az_select_gumbel_root<AMAX>(c, A, r, rc) : az_select_gumbel_interior<AMAX>(c, A, r);
-  float noise[AMAX];
+  float score[AMAX], noise[AMAX];
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
-  return az_select_puct<AMAX>(c, A, root ? 0 : 1, r, noise, rc);
+  az_puct_scores<AMAX>(c, A, r, score);
+  const int best = az_puct_argmax<AMAX>(A, root ? 0 : 1, score, noise, rc);
+  if (NOISY && c.d.noise_mode != AZ_NOISE_ZERO) {
+    const bool use_mask = root && rc.has_invalid;
+    float bs = 0.0f;
+    bool best_masked = false;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a == best) {
+        bs = score[a];
+        best_masked = use_mask && rc.invalid[a] != 0.0f;
+      }
+    if (best_masked || !(bs == bs)) ambiguous = true;  // everything masked, or NaN: let the exact rule decide
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A && a != best && !(use_mask && rc.invalid[a] != 0.0f)) {
+        const float x = score[a];
+        float m = bs < 0.0f ? -bs : bs;
+        const float ax = x < 0.0f ? -x : x;
+        m = ax > m ? ax : m;
+        m = m > 1.0f ? m : 1.0f;
+        if (!(bs - x > 4e-7f * m)) ambiguous = true;
+      }
+  }
+  return best;
 }
 
-AZ_DEV int32_t az_pack_sel(int action, int child) { return (action << 16) | (child + 1); }
+#define AZ_SEL_AMBIG (1 << 30)
+AZ_DEV int32_t az_pack_sel(int action, int child, bool ambiguous = false) {
+  return (action << 16) | (child + 1) | (ambiguous ? AZ_SEL_AMBIG : 0);
+}
+
+// The selection at `node` with the tie-break noise of visit (sim, depth), as the literal
+// search evaluates it (az_simulate_lane).  (k0, k1) is the lane's simulate key advanced to
+// `key_depth` levels; it is advanced further as needed.
+template <int AMAX, int KMAX>
+AZ_DEV int az_coop_exact_select(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b,
+                                int sim, int node, int depth, uint32_t& k0, uint32_t& k1,
+                                int& key_depth, int& child) {
+  const int A = l.A;
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, node, r);
+  if (c.d.noise_mode == AZ_NOISE_THREEFRY)
+    for (; key_depth < depth; ++key_depth) {
+      uint32_t n0, n1;
+      az_key_split(k0, k1, 0u, &n0, &n1);
+      k0 = n0;
+      k1 = n1;
+    }
+  float noise[AMAX];
+  az_puct_noise<AMAX>(c, A, b, sim, depth, k0, k1, noise);
+  key_depth = depth + 1;
+  const int act = az_select_puct<AMAX>(c, A, depth, r, noise, s.root_cache(c));
+  child = l.cidx[node * A + act];
+  return act;
+}
 
 // Before the first simulation: selection at the root of the fresh tree.
-template <int AMAX, int KMAX>
+template <int AMAX, int KMAX, bool NOISY>
 AZ_DEV void az_coop_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b) {
   const int A = l.A;
   for (int a = 0; a < A; ++a) {
@@ -176,24 +240,38 @@ AZ_DEV void az_coop_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const Co
   NodeRow<AMAX> r;
   az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
   az_node_row<AMAX, KMAX>(f, A, l.K, r);
-  const int a = az_select_cached<AMAX>(c, s, A, b, true, r);
+  bool ambiguous;
+  const int a = az_select_cached<AMAX, NOISY>(c, s, A, b, true, r, ambiguous);
   int child = AZ_UNVISITED;
 AZ_UNROLL_A
   for (int i = 0; i < AZ_TRIP_A; ++i)
     if (i == a) child = f.cidx[i];
-  s.sel[AZ_ROOT] = az_pack_sel(a, child);
+  s.sel[AZ_ROOT] = az_pack_sel(a, child, ambiguous);
 }
 
 // Step 1 (one thread per lane): follow the cached selections from the root
 // (search.py:127-187) and record the path.  Only the selection word is on the
 // dependent chain; the edge rewards / discounts of the path are gathered afterwards
 // by all threads (az_coop_fill_edges).  Returns the depth of the expanded node.
-AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
+// `sim_keys` ([S][2] words, or null): the per-simulation simulate keys (search.py:90), for
+// selections whose cached pick the tie-break noise could change.
+template <int AMAX, int KMAX, bool NOISY>
+AZ_DEV int az_coop_chase(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b, int sim,
+                         int max_depth, const uint32_t* sim_keys) {
   int node = AZ_ROOT, dep = 0, act, nxt;
+  uint32_t k0 = 0u, k1 = 0u;
+  int key_depth = -1;  // -1: the lane's key of this simulation has not been derived yet
   for (;;) {
     const int32_t e = s.sel[node];
-    act = e >> 16;
+    act = (e >> 16) & 0xff;
     nxt = (e & 0xffff) - 1;
+    if (NOISY && (e & AZ_SEL_AMBIG)) {
+      if (key_depth < 0) {
+        if (sim_keys) az_key_split(sim_keys[2 * sim], sim_keys[2 * sim + 1], (uint32_t)b, &k0, &k1);
+        key_depth = 0;
+      }
+      act = az_coop_exact_select<AMAX, KMAX>(c, l, s, b, sim, node, dep, k0, k1, key_depth, nxt);
+    }
     s.path[dep] = node | (act << 16);
     dep += 1;
     if (nxt < 0 || dep >= max_depth) break;
@@ -204,6 +282,32 @@ AZ_DEV int az_coop_chase(const CoopLds& s, int sim, int max_depth) {
   s.hdr[2] = node;
   s.hdr[3] = act;
   return dep;
+}
+
+// The simulate keys of all S simulations into `sim_keys` ([S][2] words of LDS): the rng
+// chain rng, simulate_key, expand_key = split(rng, 3) (search.py:90) is sequential, so one
+// thread walks it and the others derive their simulation's key from it.  Workgroup-wide
+// call (contains barriers).
+AZ_DEV void az_coop_sim_keys(const az_search_desc& d, uint32_t* sim_keys, int tid, int nthreads) {
+  if (tid == 0) {
+    uint32_t r0 = d.key[0], r1 = d.key[1];
+    for (int i = 0; i < d.S; ++i) {
+      sim_keys[2 * i] = r0;
+      sim_keys[2 * i + 1] = r1;
+      uint32_t n0, n1;
+      az_key_split(r0, r1, 0u, &n0, &n1);
+      r0 = n0;
+      r1 = n1;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < d.S; i += nthreads) {
+    uint32_t s0, s1;
+    az_key_split(sim_keys[2 * i], sim_keys[2 * i + 1], 1u, &s0, &s1);
+    sim_keys[2 * i] = s0;
+    sim_keys[2 * i + 1] = s1;
+  }
+  __syncthreads();
 }
 
 // Thread j of the lane's group copies the reward / discount of the path edges
@@ -265,7 +369,7 @@ AZ_UNROLL_K
   }
 }
 
-template <int AMAX, int KMAX>
+template <int AMAX, int KMAX, bool NOISY>
 AZ_DEV void az_coop_apply(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const CoopLds& s, int b,
                           int p, int dep, int newn, int parent, int action,
                           const float* ev_logits, const float* ev_value, float reward,
@@ -372,12 +476,13 @@ AZ_UNROLL_K
   // refresh the cached selection of this node
   NodeRow<AMAX> r;
   az_node_row<AMAX, KMAX>(f, A, K, r);
-  const int best = az_select_cached<AMAX>(c, s, A, b, p == 0, r);
+  bool ambiguous;
+  const int best = az_select_cached<AMAX, NOISY>(c, s, A, b, p == 0, r, ambiguous);
   int child = AZ_UNVISITED;
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a == best) child = f.cidx[a];
-  s.sel[node] = az_pack_sel(best, child);
+  s.sel[node] = az_pack_sel(best, child, ambiguous);
 }
 
 #endif  // AZ_COOP_H_

@@ -296,15 +296,14 @@ AZ_DEV RootCache az_root_inputs(const SearchCtx& c, int A, int b) {
   return rc;
 }
 
-// mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled).
+// mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled): the scores
+// value + policy before the tie-break noise is added.
 template <int AMAX>
-AZ_DEV int az_select_puct(const SearchCtx& c, int A, int depth, const NodeRow<AMAX>& r,
-                          const float (&noise)[AMAX], const RootCache& rc) {
+AZ_DEV void az_puct_scores(const SearchCtx& c, int A, const NodeRow<AMAX>& r, float (&score)[AMAX]) {
   const az_search_desc& d = c.d;
-  const bool use_mask = depth == 0 && rc.has_invalid;
   int32_t node_visit = r.node_visit;
   float pb_c = d.pb_c_init + az_logf((((float)node_visit + d.pb_c_base) + 1.0f) / d.pb_c_base);
-  float probs[AMAX], value_score[AMAX], to_argmax[AMAX];
+  float probs[AMAX], value_score[AMAX];
   if (d.variant == AZ_VARIANT_MUZERO) {
     az_softmax<AMAX>(r.logits, A, probs);
   } else {
@@ -317,12 +316,65 @@ AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) {
       float policy_score = ((sq * pb_c) * probs[a]) / (float)(r.vis[a] + 1);
-      float v = (value_score[a] + policy_score) + noise[a];
+      score[a] = value_score[a] + policy_score;
+    }
+}
+
+// argmax(score + noise) with the root-only invalid mask (action_selection.py:85-90).
+template <int AMAX>
+AZ_DEV int az_puct_argmax(int A, int depth, const float (&score)[AMAX], const float (&noise)[AMAX],
+                          const RootCache& rc) {
+  const bool use_mask = depth == 0 && rc.has_invalid;
+  float to_argmax[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      float v = score[a] + noise[a];
       // action_selection.py:90: mask = root_invalid_actions * (depth == 0)
       bool masked = use_mask && rc.invalid[a] != 0.0f;
       to_argmax[a] = masked ? -AZ_INF : v;
     }
   return az_argmax<AMAX>(to_argmax, A);
+}
+
+template <int AMAX>
+AZ_DEV int az_select_puct(const SearchCtx& c, int A, int depth, const NodeRow<AMAX>& r,
+                          const float (&noise)[AMAX], const RootCache& rc) {
+  float score[AMAX];
+  az_puct_scores<AMAX>(c, A, r, score);
+  return az_puct_argmax<AMAX>(A, depth, score, noise, rc);
+}
+
+// The tie-break noise of one selection step (action_selection.py:85, :130): 1e-7 * u.
+// THREEFRY: (k0, k1) is the lane's key at this depth; it is advanced as simulate() does
+// (search.py:155: rng_key, action_selection_key = split(rng_key)).
+template <int AMAX>
+AZ_DEV void az_puct_noise(const SearchCtx& c, int A, int b, int sim, int depth, uint32_t& k0,
+                          uint32_t& k1, float (&noise)[AMAX]) {
+  const az_search_desc& d = c.d;
+  if (d.noise_mode == AZ_NOISE_THREEFRY) {
+    uint32_t n0, n1, s0, s1;
+    az_key_split(k0, k1, 0u, &n0, &n1);
+    az_key_split(k0, k1, 1u, &s0, &s1);
+    k0 = n0;
+    k1 = n1;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A)
+        noise[a] = 1e-7f * az_uniform_from_bits(az_random_bits32(s0, s1, (uint32_t)a), 0.0f, 1.0f);
+  } else if (d.noise_mode == AZ_NOISE_INJECTED) {
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        float u = depth < d.noise_depth
+                      ? c.in.noise[(((size_t)b * d.S + sim) * d.noise_depth + depth) * A + a]
+                      : 0.0f;
+        noise[a] = 1e-7f * u;
+      }
+  } else {
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
+  }
 }
 
 // mctx_dist/_src/action_selection.py:148-200
@@ -388,29 +440,7 @@ AZ_DEV void az_simulate_lane(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int 
     az_load_row<AMAX, KMAX>(l, node, r);
     if (d.variant != AZ_VARIANT_GUMBEL) {
       float noise[AMAX];
-      if (d.noise_mode == AZ_NOISE_THREEFRY) {
-        uint32_t n0, n1, s0, s1;  // rng_key, action_selection_key = split(rng_key)
-        az_key_split(k0, k1, 0u, &n0, &n1);
-        az_key_split(k0, k1, 1u, &s0, &s1);
-        k0 = n0;
-        k1 = n1;
-AZ_UNROLL_A
-        for (int a = 0; a < AZ_TRIP_A; ++a)
-          if (a < A)
-            noise[a] = 1e-7f * az_uniform_from_bits(az_random_bits32(s0, s1, (uint32_t)a), 0.0f, 1.0f);
-      } else if (d.noise_mode == AZ_NOISE_INJECTED) {
-AZ_UNROLL_A
-        for (int a = 0; a < AZ_TRIP_A; ++a)
-          if (a < A) {
-            float u = depth < d.noise_depth
-                          ? c.in.noise[(((size_t)b * d.S + sim) * d.noise_depth + depth) * A + a]
-                          : 0.0f;
-            noise[a] = 1e-7f * u;
-          }
-      } else {
-AZ_UNROLL_A
-        for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
-      }
+      az_puct_noise<AMAX>(c, A, b, sim, depth, k0, k1, noise);
       act = az_select_puct<AMAX>(c, A, depth, r, noise, az_root_inputs(c, A, b));
     } else if (depth == 0) {
       act = az_select_gumbel_root<AMAX>(c, A, r, az_root_inputs(c, A, b));

@@ -314,7 +314,7 @@ AZ_DEV int az_opaque(int v) {
 
 // The fused search in the cooperative form (az_coop.h): all threads are tree threads
 // (16 lanes x 32 threads) and all AZ_MLP_WAVES waves run the networks.
-template <int AMAX, int KMAX>
+template <int AMAX, int KMAX, bool NOISY>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
     SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, int borrow, unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -337,13 +337,16 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
   CoopLds cs(tree_lds, ln, S, lent);
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
-  float* emb = emb_in_lds ? tree_lds + AZ_WG_LANES * az_coop_lane_words(S, borrow != 0) + ln * (S + 1) * 5 : nullptr;
+  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(tree_lds + AZ_WG_LANES * az_coop_lane_words(S, borrow != 0));
+  float* emb = emb_in_lds ? reinterpret_cast<float*>(sim_keys + 2 * S) + ln * (S + 1) * 5 : nullptr;
+  const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
+  if (need_keys) az_coop_sim_keys(d, sim_keys, tid, blockDim.x);
   az_stage_inputs(md, s, tid, blockDim.x);
   if (j == 0) {
     cs.hdr[0] = -1;
     if (active) {
       Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
-      az_coop_init<AMAX, KMAX>(c, l, cs, b);
+      az_coop_init<AMAX, KMAX, NOISY>(c, l, cs, b);
       if (emb) {
         for (int i = 0; i < 4; ++i) emb[i] = l.es[i];
         emb[4] = az_u2f((uint32_t)l.et[0]);
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
       if (leader) {
-        depth_sum += az_coop_chase(cs, sim, d.max_depth);
+        depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, cs, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
         AZ_SIM_STAMP(1);
         const int parent = cs.hdr[2], action = cs.hdr[3];
         if (emb) {
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
         }
         AZ_SIM_STAMP(6 + 3 * (it < 2 ? it : 2));
         if (mine)
-          az_coop_apply<AMAX, KMAX>(c, l, cs, b, p, dep, newn, parent, action,
+          az_coop_apply<AMAX, KMAX, NOISY>(c, l, cs, b, p, dep, newn, parent, action,
                                     s.logits + ln * AZ_MAX_ACTIONS, s.value + ln * AZ_MAX_ATOMS,
                                     reward, discount, P);
         __syncthreads();
@@ -468,15 +471,16 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   const bool can_borrow = d->S <= az_act_stride(md.pol_kp) + az_act_stride(md.val_kp);
   const int borrow = !az_coop_applicable(d, lds, false) && can_borrow && az_coop_applicable(d, lds, true);
   if (borrow || az_coop_applicable(d, lds, false)) {
-    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrow != 0) * 4;
+    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrow != 0) * 4 + (size_t)2 * d->S * 4;
     const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
     const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
     if (emb_in_lds) lds2 += emb_bytes;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
-        if (int rc = az_set_lds((const void*)k_search_fused_coop<AMAX, KMAX>, lds2)) return rc;
-        k_search_fused_coop<AMAX, KMAX>
-            <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
+        const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
+        auto kern = noisy ? k_search_fused_coop<AMAX, KMAX, true> : k_search_fused_coop<AMAX, KMAX, false>;
+        if (int rc = az_set_lds((const void*)kern, lds2)) return rc;
+        kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
                (hipStream_t)stream>>>(c, *t, md, emb_in_lds, borrow,
                                       reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();

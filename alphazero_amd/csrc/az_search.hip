@@ -100,7 +100,7 @@ AZ_UNROLL_K
 
 // The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 32
 // threads per lane, cached selections and the path in LDS.
-template <int AMAX, int KMAX>
+template <int AMAX, int KMAX, bool NOISY>
 __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
     SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
   const bool active = b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
   CoopLds s(lds, ln, S);
+  const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
+  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(lds + AZ_WG_LANES * az_coop_lane_words(S));
+  if (need_keys) az_coop_sim_keys(d, sim_keys, tid, blockDim.x);
   if (j == 0) {
     s.hdr[0] = -1;
-    if (active) az_coop_init<AMAX, KMAX>(c, l, s, b);
+    if (active) az_coop_init<AMAX, KMAX, NOISY>(c, l, s, b);
   }
   __syncthreads();
   long long depth_sum = 0;
@@ -130,7 +133,8 @@ AZ_UNROLL_K
     for (int k = 0; k < AZ_TRIP_K; ++k)
       if (k < K) ev_value[k] = inj.value[e * K + k];
     const float reward = inj.reward[e], discount = inj.discount[e];
-    if (j == 0 && active) depth_sum += az_coop_chase(s, sim, d.max_depth);
+    if (j == 0 && active)
+      depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, s, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
     __syncthreads();
     const int maxdep = az_coop_max_depth(lds, S);
     const int dep = s.hdr[0], newn = s.hdr[1], parent = s.hdr[2], action = s.hdr[3];
@@ -142,7 +146,7 @@ AZ_UNROLL_K
       if (mine) az_coop_load<AMAX, KMAX>(l, s, p, dep, newn, P);
       __syncthreads();
       if (mine)
-        az_coop_apply<AMAX, KMAX>(c, l, s, b, p, dep, newn, parent, action, ev_logits, ev_value,
+        az_coop_apply<AMAX, KMAX, NOISY>(c, l, s, b, p, dep, newn, parent, action, ev_logits, ev_value,
                                   reward, discount, P);
       __syncthreads();
     }
@@ -156,9 +160,9 @@ AZ_UNROLL_K
 bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool borrowed) {
   const char* force = getenv("AZ_FORCE_LITERAL");
   if (force && force[0] == '1') return false;
-  if (!(d->variant == AZ_VARIANT_GUMBEL || d->noise_mode == AZ_NOISE_ZERO)) return false;
   if (d->A > 8 || d->K > 8 || d->S + 1 > 65535) return false;
-  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrowed) * 4 + extra_lds_bytes;
+  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrowed) * 4 + extra_lds_bytes +
+                       (size_t)2 * d->S * 4;  // + the per-simulation keys
   return bytes <= 160 * 1024;
 }
 
@@ -171,14 +175,15 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, 0, false)) {
-    const size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4;
+    const size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + (size_t)2 * d->S * 4;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
+        const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
+        auto kern = noisy ? k_search_coop_injected<AMAX, KMAX, true> : k_search_coop_injected<AMAX, KMAX, false>;
         if (lds > 48 * 1024)
-          AZ_HIP(hipFuncSetAttribute((const void*)k_search_coop_injected<AMAX, KMAX>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_search_coop_injected<AMAX, KMAX>
-            <<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
+          AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+        kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
                (hipStream_t)stream>>>(c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;

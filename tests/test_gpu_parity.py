@@ -219,6 +219,9 @@ def test_fused_equals_callback_path(hip):
     dict(variant="gumbel", B=20, S=40, A=2, K=1, max_depth=1),
     dict(variant="gumbel", B=10, S=40, A=8, K=8),
     dict(variant="gumbel", B=24, S=256, A=2, K=1),   # paths deeper than one 32-thread group
+    dict(variant="muzero", B=40, S=64, A=3, K=2),    # PUCT with per-visit tie-break noise
+    dict(variant="sampled", B=24, S=48, A=4, K=1, with_invalid=True),
+    dict(variant="muzero", B=16, S=40, A=8, K=1, max_depth=6),
 ], ids=_ids)
 def test_literal_and_cooperative_tree_kernels_agree(hip, kw, monkeypatch):
     """The literal one-thread-per-lane kernel and the cooperative 32-threads-per-lane kernel
@@ -231,6 +234,24 @@ def test_literal_and_cooperative_tree_kernels_agree(hip, kw, monkeypatch):
     hip.assert_same(coop, literal)
     hip.assert_same(coop, runners.run_policy_c(case))
     assert coop["sum_depth"] > case["B"] * case["S"] or case.get("max_depth") == 1
+
+
+@pytest.mark.parametrize("variant", ["muzero", "sampled"])
+def test_cooperative_puct_when_only_the_noise_decides(hip, variant, monkeypatch):
+    """All priors and evaluations equal: every selection is a tie that the 1e-7 noise of
+    that very visit breaks, so the cached picks are all ambiguous and re-evaluated exactly."""
+    case = runners.synthetic_case(variant, B=24, S=32, A=4, K=1, seed=57)
+    case["prior_logits"][:] = 0.25 if variant == "sampled" else 0.0
+    case["evals"]["prior_logits"][:] = 0.25 if variant == "sampled" else 0.0
+    case["evals"]["value"][:] = 0.5
+    case["value"][:] = 0.5
+    ref = runners.run_policy_c(case)
+    coop = hip.run_policy_hip(case, "persistent")
+    hip.assert_same(coop, ref)
+    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
+    literal = hip.run_policy_hip(case, "persistent")
+    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    hip.assert_same(coop, literal)
 
 
 def test_cooperative_kernel_with_zero_noise_puct(hip, oracle):
