@@ -88,6 +88,79 @@ struct CoopLds {
   }
 };
 
+// The statistics arrays of a workgroup's lanes staged in LDS for the whole search (the
+// tree-only kernel, when they fit): the search then touches HBM twice per array -- one
+// coalesced read of the fresh tree and one coalesced write of the finished one (the 16 lanes
+// of a workgroup are contiguous in every [B, N, ...] array) -- instead of a cache line per
+// node visit.  `view()` is an az_tree over the copies, indexed by the lane's position in the workgroup.
+struct TreeLds {
+  int32_t *nv, *par, *afp, *cidx, *cvis;
+  float *raw, *nval, *clog, *crew, *cdisc, *cval;
+  int N, A, K;
+  __host__ __device__ static inline size_t words(int N, int A, int K) {
+    return (size_t)AZ_WG_LANES * N * (3 + 2 * K + A * (5 + K));
+  }
+  AZ_DEV TreeLds(float* base, int N_, int A_, int K_) : N(N_), A(A_), K(K_) {
+    const int L = AZ_WG_LANES * N;
+    int32_t* ip = reinterpret_cast<int32_t*>(base);
+    nv = ip;
+    par = ip + L;
+    afp = ip + 2 * L;
+    cidx = ip + 3 * L;
+    cvis = cidx + L * A;
+    float* fp = reinterpret_cast<float*>(cvis + L * A);
+    raw = fp;
+    nval = raw + L * K;
+    clog = nval + L * K;
+    crew = clog + L * A;
+    cdisc = crew + L * A;
+    cval = cdisc + L * A;
+  }
+  // An az_tree over the LDS copies: lane `ln` of the workgroup is its batch row `ln`.
+  // (No negative base offsets here: a pointer into LDS must stay inside the LDS window.)
+  AZ_DEV az_tree view() const {
+    az_tree v{};
+    v.node_visits = nv;
+    v.parents = par;
+    v.action_from_parent = afp;
+    v.children_index = cidx;
+    v.children_visits = cvis;
+    v.raw_values = raw;
+    v.node_values = nval;
+    v.children_prior_logits = clog;
+    v.children_rewards = crew;
+    v.children_discounts = cdisc;
+    v.children_values = cval;
+    v.emb_state = nullptr;
+    v.emb_time = nullptr;
+    return v;
+  }
+  // copies the lanes [b0, b0 + lanes) between the global tree and LDS (workgroup-wide)
+  AZ_DEV void copy(const az_tree& t, int b0, int lanes, bool to_lds, int tid, int nthreads) const {
+    const size_t o = (size_t)b0 * N;
+    const int n1 = lanes * N, nA = n1 * A, nK = n1 * K, nAK = nA * K;
+#define AZ_TL_COPY(lds_arr, glob_arr, off, count)                          \
+  for (int i = tid; i < (count); i += nthreads) {                          \
+    if (to_lds)                                                            \
+      lds_arr[i] = (glob_arr)[(off) + i];                                  \
+    else                                                                   \
+      (glob_arr)[(off) + i] = lds_arr[i];                                  \
+  }
+    AZ_TL_COPY(nv, t.node_visits, o, n1)
+    AZ_TL_COPY(par, t.parents, o, n1)
+    AZ_TL_COPY(afp, t.action_from_parent, o, n1)
+    AZ_TL_COPY(cidx, t.children_index, o * A, nA)
+    AZ_TL_COPY(cvis, t.children_visits, o * A, nA)
+    AZ_TL_COPY(raw, t.raw_values, o * K, nK)
+    AZ_TL_COPY(nval, t.node_values, o * K, nK)
+    AZ_TL_COPY(clog, t.children_prior_logits, o * A, nA)
+    AZ_TL_COPY(crew, t.children_rewards, o * A, nA)
+    AZ_TL_COPY(cdisc, t.children_discounts, o * A, nA)
+    AZ_TL_COPY(cval, t.children_values, o * A * K, nAK)
+#undef AZ_TL_COPY
+  }
+};
+
 // Every per-node word of one node, in registers.
 template <int AMAX, int KMAX>
 struct FullRow {

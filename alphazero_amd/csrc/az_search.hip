@@ -102,7 +102,7 @@ AZ_UNROLL_K
 // threads per lane, cached selections and the path in LDS.
 template <int AMAX, int KMAX, bool NOISY>
 __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
-    SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
+    SearchCtx c, az_tree t, az_injected inj, int tree_in_lds, unsigned long long* sum_depth) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
@@ -111,8 +111,15 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
   const int tid = threadIdx.x, ln = tid & (AZ_WG_LANES - 1), j = tid / AZ_WG_LANES;
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
-  Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
   CoopLds s(lds, ln, S);
+  // with room in LDS the lanes' statistics arrays are staged there for the whole search
+  const int b0 = blockIdx.x * AZ_WG_LANES;
+  const int lanes_here = d.B - b0 < AZ_WG_LANES ? d.B - b0 : AZ_WG_LANES;
+  TreeLds tl(lds + AZ_WG_LANES * az_coop_lane_words(S) + 2 * S, S + 1, A, K);
+  if (tree_in_lds) tl.copy(t, b0, lanes_here, true, tid, blockDim.x);
+  const az_tree tv = tree_in_lds ? tl.view() : t;
+  Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
+  if (tree_in_lds) __syncthreads();
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   uint32_t* sim_keys = reinterpret_cast<uint32_t*>(lds + AZ_WG_LANES * az_coop_lane_words(S));
   if (need_keys) az_coop_sim_keys(d, sim_keys, tid, blockDim.x);
@@ -151,6 +158,10 @@ AZ_UNROLL_K
       __syncthreads();
     }
   }
+  if (tree_in_lds) {
+    __syncthreads();
+    tl.copy(t, b0, lanes_here, false, tid, blockDim.x);
+  }
   az_add_depth(sum_depth, depth_sum);
 }
 
@@ -175,7 +186,10 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, 0, false)) {
-    const size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + (size_t)2 * d->S * 4;
+    size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + (size_t)2 * d->S * 4;
+    const size_t tree_bytes = TreeLds::words(d->S + 1, d->A, d->K) * 4;
+    const int tree_in_lds = lds + tree_bytes <= 160 * 1024;
+    if (tree_in_lds) lds += tree_bytes;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
         const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
@@ -184,7 +198,8 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
           AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
         kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
-               (hipStream_t)stream>>>(c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
+               (hipStream_t)stream>>>(c, *t, *inj, tree_in_lds,
+                                      reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;
       } else {
