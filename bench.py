@@ -86,6 +86,16 @@ class Actor:
         return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+    collected separately under rocprofv3 with the headline workload), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"))).get(
+            kernel + "_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def tree_kernel_roofline(B, S, A, device, reps=5):
     """The persistent tree kernel alone (injected evaluations) against the HBM roofline:
     algorithmic bytes/sim = d*(24A+56) + 2E + 4A + 32 with E = 0 (no embedding), K = 1."""
@@ -110,9 +120,9 @@ def tree_kernel_roofline(B, S, A, device, reps=5):
     t = float(np.mean(times))
     alg_bytes = sum_depth * (24 * A + 56) + B * S * (4 * A + 32)
     achieved = alg_bytes / t / 1e9
-    return {"kernel": "k_search_injected", "bound": "hbm", "achieved": round(achieved, 2),
+    return {"kernel": "k_search_coop_injected", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
-            "traffic": None, "ms_per_launch": round(t * 1e3, 4),
+            "traffic": pmc_traffic("k_search_coop_injected"), "ms_per_launch": round(t * 1e3, 4),
             "mean_depth": round(sum_depth / (B * S), 3),
             "sims_per_s": round(B * S / t, 1)}
 
@@ -202,16 +212,11 @@ def main():
             "env_steps_per_s": round(total_sims / S / elapsed, 1),
             "roofline": {"kernel": "k_search_fused", "bound": "mfma", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
+                         "traffic": pmc_traffic("k_search_fused"),
                          "ms_per_launch": round(kt * 1e3, 4),
                          "mean_depth": round(sum_depth / (B * S), 3)},
         }
-        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                line["roofline"]["traffic"] = json.load(open(pmc)).get("k_search_fused_bytes_per_launch")
-            except Exception:
-                pass
         if world == 1:
             line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
             if not args.no_cpu_baseline:
