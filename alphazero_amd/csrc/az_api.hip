@@ -11,6 +11,7 @@
 
 #include "az_host.h"
 #include "az_envs.h"
+#include "az_swish.h"
 
 // ---------------------------------------------------------------------------
 // error channel
@@ -551,8 +552,25 @@ __global__ void k_math_apply(int fn, int n, const float* __restrict__ x, float* 
   y[i] = r;
 }
 
+// fn = 8: swish as the dense layers' epilogue evaluates it (four values per thread)
+__global__ void k_swish_packed(int n, const float* __restrict__ x, float* __restrict__ y) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float v[4];
+  for (int j = 0; j < 4; ++j) v[j] = i + j < n ? x[i + j] : 0.0f;
+  const az_f32x2 a = az_swish2(az_f32x2{v[0], v[1]}), b = az_swish2(az_f32x2{v[2], v[3]});
+  const float r[4] = {a.x, a.y, b.x, b.y};
+  for (int j = 0; j < 4; ++j)
+    if (i + j < n) y[i + j] = r[j];
+}
+
 extern "C" int az_math_apply(int32_t fn, int32_t n, const float* x, float* y, void* stream) {
   if (n < 1 || !x || !y) return az_fail(AZ_ERR_INVALID, "bad math_apply arguments");
+  if (fn == 8) {
+    k_swish_packed<<<dim3((n + 1023) / 1024), dim3(256), 0, (hipStream_t)stream>>>(n, x, y);
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  }
   k_math_apply<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(fn, n, x, y);
   AZ_LAUNCH_CHECK();
   return AZ_OK;

@@ -201,8 +201,17 @@ AZ_HD float az_cosf(float x) {
   return neg ? -y : y;
 }
 
-/* logistic(x) = 1 / (1 + exp(-x));  swish(x) = x * logistic(x). */
-AZ_HD float az_logistic(float x) { return 1.0f / (1.0f + az_expf(-x)); }
+/* logistic(x) = 1 / (1 + exp(t)) with t = -x clamped to [-64, 64];  swish(x) = x * logistic(x).
+ * The clamp is part of the specification: it moves the result by less than 2e-28 (logistic is
+ * below 1.6e-28 for x < -64 and rounds to 1 for x > 17), and it keeps exp(t), 1 + exp(t) and
+ * the quotient normal numbers far from over- and underflow, so that the GPU's packed form
+ * (az_swish.h) needs no range handling at all.  A NaN passes through the clamp. */
+AZ_HD float az_logistic(float x) {
+  float t = -x;
+  t = t < -64.0f ? -64.0f : t;
+  t = t > 64.0f ? 64.0f : t;
+  return 1.0f / (1.0f + az_expf(t));
+}
 AZ_HD float az_swish(float x) { return x * az_logistic(x); }
 /* x ** e for x >= 0 as exp(e * log(x)); e == 0 gives exactly 1 (also for
  * x == 0), matching the power function's convention. */

@@ -35,6 +35,7 @@
 #define AZ_MLP_H_
 
 #include "az_device.h"
+#include "az_swish.h"
 
 typedef __attribute__((ext_vector_type(4))) float az_f32x4;
 
@@ -334,49 +335,6 @@ __device__ long long az_stamps[8][64];
 struct MlpRegs {
   az_f32x4 W0[AZ_SLOTS], W1[AZ_SLOTS], W2[AZ_RIDER_SLOTS];
 };
-
-typedef __attribute__((ext_vector_type(2))) float az_f32x2;
-
-AZ_DEV az_f32x2 az_fma2(az_f32x2 a, az_f32x2 b, az_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-AZ_DEV az_f32x2 az_splat2(float v) { return az_f32x2{v, v}; }
-
-// az_swish (az_math.h) on two values at once: the same IEEE operations per element in
-// the same order, written on 2-vectors so that the multiplies, adds and fused
-// multiply-adds become packed instructions (half the vector-ALU issue slots).
-AZ_DEV az_f32x2 az_swish2(az_f32x2 x) {
-  const az_f32x2 t = -x;  // logistic(x) = 1 / (1 + exp(-x))
-  const bool nan0 = t.x != t.x, nan1 = t.y != t.y;
-  const bool ov0 = t.x > 88.72283935546875f, ov1 = t.y > 88.72283935546875f;
-  const bool un0 = t.x < -103.97208404541015625f, un1 = t.y < -103.97208404541015625f;
-  az_f32x2 xs;
-  xs.x = (nan0 | ov0 | un0) ? 0.0f : t.x;
-  xs.y = (nan1 | ov1 | un1) ? 0.0f : t.y;
-  const az_f32x2 kf = (xs * az_splat2(1.44269502162933349609375f) + az_splat2(12582912.0f)) - az_splat2(12582912.0f);
-  az_f32x2 r = az_fma2(kf, az_splat2(-0.693359375f), xs);
-  r = az_fma2(kf, az_splat2(2.12194440e-4f), r);
-  az_f32x2 p = az_splat2(1.9875691500e-4f);
-  p = az_fma2(p, r, az_splat2(1.3981999507e-3f));
-  p = az_fma2(p, r, az_splat2(8.3334519073e-3f));
-  p = az_fma2(p, r, az_splat2(4.1665795894e-2f));
-  p = az_fma2(p, r, az_splat2(1.6666665459e-1f));
-  p = az_fma2(p, r, az_splat2(5.0000001201e-1f));
-  p = az_fma2(p, r * r, r);
-  p = p + az_splat2(1.0f);
-  const int k0 = (int)kf.x, k1 = (int)kf.y;
-  const int k0a = k0 >> 1, k1a = k1 >> 1;
-  const az_f32x2 s1 = {az_pow2i(k0a), az_pow2i(k1a)};
-  const az_f32x2 s2 = {az_pow2i(k0 - k0a), az_pow2i(k1 - k1a)};
-  az_f32x2 e = (p * s1) * s2;
-  e.x = un0 ? 0.0f : e.x;
-  e.y = un1 ? 0.0f : e.y;
-  e.x = ov0 ? AZ_INF : e.x;
-  e.y = ov1 ? AZ_INF : e.y;
-  e.x = nan0 ? t.x : e.x;
-  e.y = nan1 ? t.y : e.y;
-  const az_f32x2 d = az_splat2(1.0f) + e;
-  const az_f32x2 l = {1.0f / d.x, 1.0f / d.y};
-  return x * l;
-}
 
 // One output tile's epilogue.  C/D fragment: column = lane & 15, row = (lane >> 4) * 4 + r.
 AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& acc, float bn,

@@ -27,21 +27,30 @@ def hip():
 # ---------------------------------------------------------------- numerics spec
 @pytest.mark.parametrize("fn,lo,hi", [("exp", -110.0, 90.0), ("log", 0.0, 1e30), ("sin", -40.0, 40.0),
                                       ("cos", -40.0, 40.0), ("swish", -100.0, 100.0),
-                                      ("sqrt", 0.0, 1e30), ("rcp", -1e3, 1e3)])
+                                      ("sqrt", 0.0, 1e30), ("rcp", -1e3, 1e3),
+                                      ("swish_packed", -100.0, 100.0), ("swish_packed", -8.0, 8.0)])
 def test_numerics_spec_host_device_bits(hip, oracle, fn, lo, hi):
-    """Every elementary function gives the same bits on the host and on gfx950."""
+    """Every elementary function gives the same bits on the host and on gfx950.
+    swish_packed is swish the way the dense layers' epilogue issues it (packed pairs, a
+    shorter form for |x| <= 64): checked against the same host function."""
     from alphazero_amd import _native as nat
     rng = np.random.default_rng(0)
     x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
     if fn in ("log", "sqrt"):
         x = np.exp(rng.uniform(-100, 69, 1 << 20)).astype(np.float32)
     x[:8] = [0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38]
+    if fn == "swish_packed":
+        # the switch-over points, tiny and subnormal inputs, and magnitudes spread over all exponents
+        x[8:16] = [64.0, -64.0, np.nextafter(np.float32(64), np.float32(65)),
+                   -np.nextafter(np.float32(64), np.float32(65)), 1e-38, -1e-38, 1e-42, -88.8]
+        n = 1 << 16
+        x[16:16 + n] = (np.exp(rng.uniform(-100, 4.2, n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
     xd = hip.dev(x)
     yd = torch.empty_like(xd)
-    code = oracle._MATH_FN[fn]
+    code = 8 if fn == "swish_packed" else oracle._MATH_FN[fn]
     nat.check(nat.lib().az_math_apply(code, x.size, nat.ptr(xd), nat.ptr(yd), nat.stream_ptr()))
     y = yd.cpu().numpy()
-    ref = oracle.math_apply(fn, x)
+    ref = oracle.math_apply("swish" if fn == "swish_packed" else fn, x)
     same = (y.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(y) & np.isnan(ref))
     assert same.all(), (fn, x[~same][:5], y[~same][:5], ref[~same][:5])
 
