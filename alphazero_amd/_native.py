@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaz_mcts.so")
+# AZ_MCTS_LIB selects another build of the same library (diagnostic builds under tools/probes)
+LIB_PATH = os.environ.get("AZ_MCTS_LIB") or os.path.join(_HERE, "libaz_mcts.so")
 
 MAX_LAYERS = 8
 MAX_ACTIONS = 64
