@@ -96,6 +96,15 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_mfma_util(kernel):
+    """Matrix-pipe busy share of `kernel` from the committed SQ counter pass, or None."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_counters.json")))["kernels"]
+        return next((round(v["mfma_util"], 4) for k, v in ks.items() if kernel in k), None)
+    except Exception:
+        return None
+
+
 def tree_kernel_roofline(B, S, A, device, reps=5):
     """The persistent tree kernel alone (injected evaluations) against the HBM roofline:
     algorithmic bytes/sim = d*(24A+56) + 2E + 4A + 32 with E = 0 (no embedding), K = 1."""
@@ -214,6 +223,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
                          "traffic": pmc_traffic("k_search_fused"),
+                         "mfma_util_pmc": pmc_mfma_util("k_search_fused_coop"),
                          "ms_per_launch": round(kt * 1e3, 4),
                          "mean_depth": round(sum_depth / (B * S), 3)},
         }

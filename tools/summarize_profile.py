@@ -1,6 +1,6 @@
 """Condenses rocprofv3 output directories into the small files committed under profiles/.
 
-usage: summarize_profile.py <round-tag> <stats_dir> [<fetch_pmc_dir> <write_pmc_dir>]
+usage: summarize_profile.py <round-tag> <stats_dir> [<fetch_pmc_dir> <write_pmc_dir> [<sq_pmc_dir>]]
 """
 import csv, glob, json, os, sys, collections
 
@@ -47,3 +47,26 @@ if len(sys.argv) >= 5:
                 res[kern + "_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
     json.dump(res, open(os.path.join(root, f"{tag}_hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1)[:3000])
+
+if len(sys.argv) >= 6:
+    # SQ / GRBM pass: matrix-pipe busy cycles against the kernel's active cycles.  rocprofv3 reports
+    # GRBM_GUI_ACTIVE summed over the 8 XCDs; the chip has 256 CUs x 4 SIMDs.
+    cc = find(sys.argv[5], "counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(cc)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "k_search" in k or "k_forward" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {"note": "mean per launch; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); "
+                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves", "kernels": {}}
+    for k, c in agg.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        if m.get("GRBM_GUI_ACTIVE"):
+            m["mfma_util"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        if m.get("SQ_WAVE_CYCLES"):
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if n in m:
+                    m[n + "_share_of_wave_cycles"] = m[n] / m["SQ_WAVE_CYCLES"]
+        out["kernels"][k] = m
+    json.dump(out, open(os.path.join(root, f"{tag}_sq_counters.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1)[:3000])
