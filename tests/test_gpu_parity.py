@@ -102,6 +102,10 @@ INJECTED_CASES = [
     dict(variant="muzero", B=8, S=16, A=20, K=12),
     dict(variant="sampled", B=32, S=16, A=4, K=8),
     dict(variant="sampled", B=16, S=24, A=3, K=1, with_invalid=True),
+    # smallest shapes: one lane, one simulation, one action; a ragged last workgroup
+    dict(variant="gumbel", B=1, S=1, A=2, K=1),
+    dict(variant="muzero", B=17, S=1, A=1, K=1),
+    dict(variant="gumbel", B=3, S=5, A=1, K=2),
 ]
 _ids = lambda k: "-".join(f"{a}{b}" for a, b in k.items())  # noqa: E731
 
