@@ -107,8 +107,10 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
   // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
-  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share wave 0
-  const int tid = threadIdx.x, ln = tid & (AZ_WG_LANES - 1), j = tid / AZ_WG_LANES;
+  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share one wave --
+  // the last one: the root's selection rule and the interior one are different code, and this
+  // way they run in different waves at the same time
+  const int tid = threadIdx.x, ln = tid & (AZ_WG_LANES - 1), j = (tid / AZ_WG_LANES + 1) & (AZ_GROUP - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
   CoopLds s(lds, ln, S);
