@@ -357,6 +357,44 @@ AZ_DEV int az_coop_chase(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const Co
   return dep;
 }
 
+// Workgroup barrier that publishes LDS writes only: global loads that were requested before it
+// stay in flight (a plain __syncthreads() waits for them).
+AZ_DEV void az_coop_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// The same walk for the rules without per-visit noise, written so that every lane of the wave
+// runs every iteration under a predicate and the loop ends on one scalar test (no lane ever
+// leaves the loop early): the walk is one dependent LDS read per level, and in the plain form
+// above the execution-mask bookkeeping of the divergent loop costs more than that read.
+AZ_DEV int az_coop_chase_lean(const CoopLds& s, int sim, int max_depth, bool active) {
+  int node = active ? AZ_ROOT : -1;  // -1: this lane's walk has ended
+  int dep = 0, act = 0, nxt = 0, last = AZ_ROOT;
+  for (;;) {
+    const bool live = node >= 0;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+    const int32_t e = s.sel[live ? node : AZ_ROOT];  // a finished lane reads its root again, unused
+    const int a = (e >> 16) & 0xff, n = (e & 0xffff) - 1;
+    // selects instead of branches; a finished lane's store goes to the unused header word
+    int32_t* dst = live ? s.path + dep : s.hdr + 6;
+    *dst = node | (a << 16);
+    last = live ? node : last;
+    act = live ? a : act;
+    nxt = live ? n : nxt;
+    dep += live ? 1 : 0;
+    node = (live && dep < max_depth) ? n : -1;  // n == -1: the edge is unvisited, the walk ends
+  }
+  if (active) {
+    s.hdr[0] = dep;
+    s.hdr[1] = nxt < 0 ? sim + 1 : nxt;  // search.py:97-99
+    s.hdr[2] = last;
+    s.hdr[3] = act;
+  }
+  return dep;
+}
+
 // The simulate keys of all S simulations into `sim_keys` ([S][2] words of LDS): the rng
 // chain rng, simulate_key, expand_key = split(rng, 3) (search.py:90) is sequential, so one
 // thread walks it and the others derive their simulation's key from it.  Workgroup-wide

@@ -98,11 +98,32 @@ AZ_UNROLL_K
   az_add_depth(sum_depth, depth_sum);
 }
 
+#ifdef AZ_STAMP
+// Diagnostic build only: cycle stamps of the leader of lane 0 in workgroup 0, one row per simulation.
+__device__ long long az_tree_stamps[64][8];
+#define AZ_TREE_STAMP(k)                                                                                   \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && j == 0 && ln == 0 && sim < 64) az_tree_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int az_debug_read_tree_stamps(long long* host_out) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_tree_stamps), sizeof(long long) * 64 * 8));
+  return AZ_OK;
+}
+#else
+#define AZ_TREE_STAMP(k) \
+  do {                   \
+  } while (0)
+#endif
+
 // The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 32
 // threads per lane, cached selections and the path in LDS.
-template <int AMAX, int KMAX, bool NOISY>
+// TREE_LDS: the statistics arrays are staged in LDS for the whole search (a template parameter
+// so that the compiler sees LDS addresses and emits LDS instructions, not generic ones).
+template <int AMAX, int KMAX, bool NOISY, bool TREE_LDS>
 __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
-    SearchCtx c, az_tree t, az_injected inj, int tree_in_lds, unsigned long long* sum_depth) {
+    SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
+  constexpr int tree_in_lds = TREE_LDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
@@ -131,20 +152,44 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
   }
   __syncthreads();
   long long depth_sum = 0;
-  for (int sim = 0; sim < S; ++sim) {
-    // the recurrent_fn outputs of this (lane, simulation)
-    const size_t e = (size_t)(active ? b : 0) * S + sim;
-    float ev_logits[AMAX], ev_value[KMAX];
+  float ev_logits[AMAX], ev_value[KMAX], reward, discount;
+  float nx_logits[AMAX], nx_value[KMAX], nx_reward, nx_discount;
+  {
+    const size_t e = (size_t)(active ? b : 0) * S;
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a)
       if (a < A) ev_logits[a] = inj.prior_logits[e * A + a];
 AZ_UNROLL_K
     for (int k = 0; k < AZ_TRIP_K; ++k)
       if (k < K) ev_value[k] = inj.value[e * K + k];
-    const float reward = inj.reward[e], discount = inj.discount[e];
-    if (j == 0 && active)
-      depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, s, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
-    __syncthreads();
+    reward = inj.reward[e];
+    discount = inj.discount[e];
+  }
+  for (int sim = 0; sim < S; ++sim) {
+    AZ_TREE_STAMP(0);
+    if (NOISY) {
+      if (j == 0 && active)
+        depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, s, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
+    } else if (j == 0) {  // the whole leader wave walks together (inactive lanes under a false predicate)
+      depth_sum += az_coop_chase_lean(s, sim, d.max_depth, active);
+    }
+    AZ_TREE_STAMP(1);
+    // the recurrent_fn outputs of the NEXT simulation of this lane are requested here, a whole
+    // simulation before the update that consumes them, so that their latency is never waited for
+    {
+      const int sn = sim + 1 < S ? sim + 1 : sim;
+      const size_t e = (size_t)(active ? b : 0) * S + sn;
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < A) nx_logits[a] = inj.prior_logits[e * A + a];
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) nx_value[k] = inj.value[e * K + k];
+      nx_reward = inj.reward[e];
+      nx_discount = inj.discount[e];
+    }
+    az_coop_lds_barrier();  // the walk's results live in LDS; the loads above stay in flight
+    AZ_TREE_STAMP(2);
     const int maxdep = az_coop_max_depth(lds, S);
     const int dep = s.hdr[0], newn = s.hdr[1], parent = s.hdr[2], action = s.hdr[3];
     if (active) az_coop_fill_edges(s, j, dep);
@@ -153,12 +198,24 @@ AZ_UNROLL_K
       const bool mine = active && p <= dep;
       CoopPos<AMAX, KMAX> P;
       if (mine) az_coop_load<AMAX, KMAX>(l, s, p, dep, newn, P);
-      __syncthreads();
+      if (it == 0) AZ_TREE_STAMP(3);
+      // with the statistics in LDS nothing the other threads need is in global memory, and a
+      // barrier that only publishes LDS keeps the prefetch above in flight
+      if (TREE_LDS) az_coop_lds_barrier(); else __syncthreads();
+      if (it == 0) AZ_TREE_STAMP(4);
       if (mine)
         az_coop_apply<AMAX, KMAX, NOISY>(c, l, s, b, p, dep, newn, parent, action, ev_logits, ev_value,
                                   reward, discount, P);
-      __syncthreads();
+      if (it == 0) AZ_TREE_STAMP(5);
+      if (TREE_LDS) az_coop_lds_barrier(); else __syncthreads();
+      if (it == 0) AZ_TREE_STAMP(6);
     }
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a) ev_logits[a] = nx_logits[a];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k) ev_value[k] = nx_value[k];
+    reward = nx_reward;
+    discount = nx_discount;
   }
   if (tree_in_lds) {
     __syncthreads();
@@ -195,12 +252,15 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
         const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-        auto kern = noisy ? k_search_coop_injected<AMAX, KMAX, true> : k_search_coop_injected<AMAX, KMAX, false>;
+        auto kern = noisy ? (tree_in_lds ? k_search_coop_injected<AMAX, KMAX, true, true>
+                                         : k_search_coop_injected<AMAX, KMAX, true, false>)
+                          : (tree_in_lds ? k_search_coop_injected<AMAX, KMAX, false, true>
+                                         : k_search_coop_injected<AMAX, KMAX, false, false>);
         if (lds > 48 * 1024)
           AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
         kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
-               (hipStream_t)stream>>>(c, *t, *inj, tree_in_lds,
+               (hipStream_t)stream>>>(c, *t, *inj,
                                       reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;
