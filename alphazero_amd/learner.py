@@ -185,16 +185,27 @@ class ClipAdam:
 
     @torch.no_grad()
     def step(self, grads):
-        gnorm = torch.sqrt(sum((g * g).sum() for g in grads))
+        """`grads`: one tensor per parameter leaf (views of one flat buffer are fine).  The update
+        runs as multi-tensor operations -- a dozen launches for all leaves instead of eight
+        per leaf; element by element the arithmetic is that of optax's clip + adam."""
+        grads = list(grads)
+        gnorm = torch.sqrt(torch.stack([s.sum() for s in torch._foreach_mul(grads, grads)]).sum())
         scale = torch.where(gnorm < self.max_norm, torch.ones_like(gnorm), self.max_norm / gnorm)
         lr = self.learning_rate()
         t = self.count + 1
         c1, c2 = 1 - self.b1 ** t, 1 - self.b2 ** t
-        for p, g, m, v in zip(self.params, grads, self.m, self.v):
-            g = g * scale
-            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
-            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
-            p.sub_(lr * (m / c1) / ((v / c2).sqrt() + self.eps))
+        g = torch._foreach_mul(grads, scale)
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, g, alpha=1 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, g, g, value=1 - self.b2)
+        upd = torch._foreach_div(self.m, c1)
+        torch._foreach_mul_(upd, lr)
+        den = torch._foreach_div(self.v, c2)
+        torch._foreach_sqrt_(den)
+        torch._foreach_add_(den, self.eps)
+        torch._foreach_div_(upd, den)
+        torch._foreach_sub_(self.params, upd)
         self.count += 1
         return gnorm
 
