@@ -267,6 +267,13 @@ def test_numerics_spec_special_values(oracle):
     small = np.array([1.1754944e-38, 1e-45], np.float32)  # smallest normal, smallest subnormal
     np.testing.assert_allclose(l[3:], np.log(small.astype(np.float64)), rtol=1e-6)
     assert np.isnan(oracle.math_apply("log", np.array([-1], np.float32))[0])
+    # swish = x * logistic(x), the logistic's exponent clamped to [-64, 64] by specification
+    sw = oracle.math_apply("swish", np.array([0, 100, -100, inf, -inf, 64, -64, np.nan], np.float32))
+    assert sw[0] == 0 and sw[1] == 100 and sw[3] == inf and sw[4] == -inf and np.isnan(sw[7])
+    tail = 1.0 / (1.0 + np.exp(64.0))                      # logistic at the clamp
+    np.testing.assert_allclose(sw[2], -100 * tail, rtol=1e-6)
+    np.testing.assert_allclose(sw[6], -64 * tail, rtol=1e-6)
+    assert sw[5] == 64 and abs(sw[2]) < 2e-26              # the clamp moves results by < 2e-26
     # subnormal results of exp are rounded once
     x = np.linspace(-103.9, -87.4, 1000).astype(np.float32)
     y = oracle.math_apply("exp", x).astype(np.float64)
