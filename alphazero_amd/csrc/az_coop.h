@@ -372,19 +372,23 @@ AZ_DEV void az_coop_lds_barrier() {
 AZ_DEV int az_coop_chase_lean(const CoopLds& s, int sim, int max_depth, bool active) {
   int node = active ? AZ_ROOT : -1;  // -1: this lane's walk has ended
   int dep = 0, act = 0, nxt = 0, last = AZ_ROOT;
-  for (;;) {
-    const bool live = node >= 0;
-    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-    const int32_t e = s.sel[live ? node : AZ_ROOT];  // a finished lane reads its root again, unused
-    const int a = (e >> 16) & 0xff, n = (e & 0xffff) - 1;
-    // selects instead of branches; a finished lane's store goes to the unused header word
-    int32_t* dst = live ? s.path + dep : s.hdr + 6;
-    *dst = node | (a << 16);
-    last = live ? node : last;
-    act = live ? a : act;
-    nxt = live ? n : nxt;
-    dep += live ? 1 : 0;
-    node = (live && dep < max_depth) ? n : -1;  // n == -1: the edge is unvisited, the walk ends
+  // four levels per exit test: the test (vector compare -> scalar branch) is as long as the LDS
+  // round trip it guards, and a finished lane's extra levels are harmless
+  while (__builtin_amdgcn_ballot_w64(node >= 0) != 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = node >= 0;
+      const int32_t e = s.sel[live ? node : AZ_ROOT];  // a finished lane reads its root again, unused
+      const int a = (e >> 16) & 0xff, n = (e & 0xffff) - 1;
+      // selects instead of branches; a finished lane's store goes to the unused header word
+      int32_t* dst = live ? s.path + dep : s.hdr + 6;
+      *dst = node | (a << 16);
+      last = live ? node : last;
+      act = live ? a : act;
+      nxt = live ? n : nxt;
+      dep += live ? 1 : 0;
+      node = (live && dep < max_depth) ? n : -1;  // n == -1: the edge is unvisited, the walk ends
+    }
   }
   if (active) {
     s.hdr[0] = dep;
