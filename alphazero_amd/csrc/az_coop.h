@@ -370,27 +370,29 @@ AZ_DEV void az_coop_lds_barrier() {
 // leaves the loop early): the walk is one dependent LDS read per level, and in the plain form
 // above the execution-mask bookkeeping of the divergent loop costs more than that read.
 AZ_DEV int az_coop_chase_lean(const CoopLds& s, int sim, int max_depth, bool active) {
+  // One wave alone on its SIMD issues an instruction every four cycles or so, so the cost of a
+  // level is its instruction count as much as the LDS round trip: the loop carries only the
+  // node and the depth; the last edge is read back from the recorded path afterwards.
   int node = active ? AZ_ROOT : -1;  // -1: this lane's walk has ended
-  int dep = 0, act = 0, nxt = 0, last = AZ_ROOT;
+  int dep = 0;
+  s.hdr[6] = 0;  // what a finished lane reads instead of a selection word: "no child"
   // four levels per exit test: the test (vector compare -> scalar branch) is as long as the LDS
   // round trip it guards, and a finished lane's extra levels are harmless
   while (__builtin_amdgcn_ballot_w64(node >= 0) != 0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool live = node >= 0;
-      const int32_t e = s.sel[live ? node : AZ_ROOT];  // a finished lane reads its root again, unused
-      const int a = (e >> 16) & 0xff, n = (e & 0xffff) - 1;
-      // selects instead of branches; a finished lane's store goes to the unused header word
-      int32_t* dst = live ? s.path + dep : s.hdr + 6;
-      *dst = node | (a << 16);
-      last = live ? node : last;
-      act = live ? a : act;
-      nxt = live ? n : nxt;
+      const int32_t e = *(live ? s.sel + node : s.hdr + 6);
+      const int a = (e >> 16) & 0xff, n = (e & 0xffff) - 1;  // n == -1: unvisited edge, or finished
+      s.path[dep] = node | (a << 16);  // a finished lane scribbles on the entry past its path's end
       dep += live ? 1 : 0;
-      node = (live && dep < max_depth) ? n : -1;  // n == -1: the edge is unvisited, the walk ends
+      node = dep < max_depth ? n : -1;
     }
   }
   if (active) {
+    const int32_t pe = s.path[dep - 1];
+    const int last = pe & 0xffff, act = (pe >> 16) & 0xff;
+    const int nxt = (s.sel[last] & 0xffff) - 1;
     s.hdr[0] = dep;
     s.hdr[1] = nxt < 0 ? sim + 1 : nxt;  // search.py:97-99
     s.hdr[2] = last;
