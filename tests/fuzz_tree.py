@@ -1,5 +1,6 @@
 """Random shapes of the tree-only search through the C ABI against the plain-C checker
-(differential run; prints the first mismatch).  usage: fuzz_tree.py [n_cases] [seed]"""
+(differential run; prints the first mismatch).  usage: python tests/fuzz_tree.py [n_cases] [seed]
+(not collected by pytest; it lives here because it uses the checker)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
