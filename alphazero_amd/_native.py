@@ -35,6 +35,7 @@ class SearchDesc(C.Structure):
         ("min_value", C.c_float), ("max_value", C.c_float),
         ("max_num_considered", C.c_int32), ("noise_mode", C.c_int32),
         ("noise_depth", C.c_int32), ("key", C.c_uint32 * 2),
+        ("kernel_form", C.c_int32),
     ]
 
 

@@ -377,13 +377,13 @@ AZ_UNROLL_A
   }
 }
 
-// mctx_dist/_src/action_selection.py:148-200
+// mctx_dist/_src/action_selection.py:148-200 after the qtransform: `cq` are the completed
+// Q-values of the root row.
 template <int AMAX>
-AZ_DEV int az_select_gumbel_root(const SearchCtx& c, int A, const NodeRow<AMAX>& r,
-                                 const RootCache& rc) {
+AZ_DEV int az_gumbel_root_tail(const SearchCtx& c, int A, const NodeRow<AMAX>& r, const float (&cq)[AMAX],
+                               const RootCache& rc) {
   const az_search_desc& d = c.d;
-  float cq[AMAX], score[AMAX];
-  az_qtransform<AMAX>(d, A, r, cq);
+  float score[AMAX];
   float nvalid = 0.0f;
   int32_t sim_index = 0;
 AZ_UNROLL_A
@@ -406,11 +406,18 @@ AZ_UNROLL_A
   return az_argmax<AMAX>(score, A);
 }
 
-// mctx_dist/_src/action_selection.py:203-240, 256-277
 template <int AMAX>
-AZ_DEV int az_select_gumbel_interior(const SearchCtx& c, int A, const NodeRow<AMAX>& r) {
-  float cq[AMAX], x[AMAX], probs[AMAX], to_argmax[AMAX];
+AZ_DEV int az_select_gumbel_root(const SearchCtx& c, int A, const NodeRow<AMAX>& r,
+                                 const RootCache& rc) {
+  float cq[AMAX];
   az_qtransform<AMAX>(c.d, A, r, cq);
+  return az_gumbel_root_tail<AMAX>(c, A, r, cq, rc);
+}
+
+// mctx_dist/_src/action_selection.py:203-240, 256-277 after the qtransform.
+template <int AMAX>
+AZ_DEV int az_gumbel_interior_tail(int A, const NodeRow<AMAX>& r, const float (&cq)[AMAX]) {
+  float x[AMAX], probs[AMAX], to_argmax[AMAX];
   int32_t sum_visits = 0;
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -423,6 +430,13 @@ AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) to_argmax[a] = probs[a] - (float)r.vis[a] / (float)(1 + sum_visits);
   return az_argmax<AMAX>(to_argmax, A);
+}
+
+template <int AMAX>
+AZ_DEV int az_select_gumbel_interior(const SearchCtx& c, int A, const NodeRow<AMAX>& r) {
+  float cq[AMAX];
+  az_qtransform<AMAX>(c.d, A, r, cq);
+  return az_gumbel_interior_tail<AMAX>(A, r, cq);
 }
 
 // mctx_dist/_src/search.py:127-187 with the root/interior switch of

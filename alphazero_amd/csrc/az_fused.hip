@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "az_host.h"
-#include "az_coop.h"
+#include "az_wave.h"
 #include "az_envs.h"
 #include "az_mlp.h"
 
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
 __device__ long long az_sim_stamps[64][16];
 #define AZ_SIM_STAMP(k)                                                                        \
   do {                                                                                         \
-    if (blockIdx.x == 0 && j == 0 && ln == 0 && sim < 64) az_sim_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x == 0 && tid == 0 && sim < 64) az_sim_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define AZ_SIM_STAMP(k) \
@@ -312,41 +312,38 @@ AZ_DEV int az_opaque(int v) {
   return v;
 }
 
-// The fused search in the cooperative form (az_coop.h): all threads are tree threads
-// (16 lanes x 32 threads) and all AZ_MLP_WAVES waves run the networks.
+// The fused search in the cooperative form (az_wave.h): all threads are tree threads (16 lanes
+// x 32 path positions, two lanes per wave) and all AZ_MLP_WAVES waves run the networks.  Per
+// simulation: every wave walks its two lanes' trees and steps their environments, one
+// workgroup barrier hands the 16 observations to the networks, and after the networks' last
+// phase every wave updates its own two lanes -- nothing else in the loop crosses a wave.
 template <int AMAX, int KMAX, bool NOISY>
-__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
-    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, int borrow, unsigned long long* sum_depth) {
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
+    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
+  static_assert(AZ_MLP_WAVES * 64 == AZ_TREE_THREADS, "one thread layout for both phases");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
   MlpLds s(lds, md.pol_kp, md.val_kp);
   float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp);
-  // `borrow`: the path's edge rewards / discounts are kept in the networks' activation
-  // buffers, which are free between two evaluations (needed when S is large)
-  float* lent = borrow ? s.pa : nullptr;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
-  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share wave 0
-  // (the last wave takes position 0: the root's selection rule and the interior one are
-  // different code, and this way they run in different waves at the same time)
-  const int ln = tid & (AZ_WG_LANES - 1), j = (tid / AZ_WG_LANES + 1) & (AZ_GROUP - 1);
+  const int ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
   const bool leader = active && j == 0;
-  CoopLds cs(tree_lds, ln, S, lent);
+  WaveLds ws(tree_lds, ln, S);
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
-  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(tree_lds + AZ_WG_LANES * az_coop_lane_words(S, borrow != 0));
+  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(tree_lds + AZ_WG_LANES * WaveLds::lane_words(S));
   float* emb = emb_in_lds ? reinterpret_cast<float*>(sim_keys + 2 * S) + ln * (S + 1) * 5 : nullptr;
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
-  if (need_keys) az_coop_sim_keys(d, sim_keys, tid, blockDim.x);
+  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
   az_stage_inputs(md, s, tid, blockDim.x);
   if (j == 0) {
-    cs.hdr[0] = -1;
+    ws.selx[0] = 0;
     if (active) {
       Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
-      az_coop_init<AMAX, KMAX, NOISY>(c, l, cs, b);
+      az_wave_init<AMAX, KMAX, NOISY>(c, l, ws, b);
       if (emb) {
         for (int i = 0; i < 4; ++i) emb[i] = l.es[i];
         emb[4] = az_u2f((uint32_t)l.et[0]);
@@ -357,96 +354,69 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_coop(
   __syncthreads();
   int depth_sum = 0;
   for (int sim = 0; sim < S; ++sim) {
-    EnvState st;
     AZ_SIM_STAMP(0);
     MlpRegs regs;
-    constexpr bool kPrefetch = sizeof(CoopPos<AMAX, KMAX>) <= 32 * 4;
-    CoopPos<AMAX, KMAX> P0;
-    int dep, newn;
+    constexpr bool kPrefetch = sizeof(WaveRow<AMAX, KMAX>) <= 34 * 4;
+    WaveRow<AMAX, KMAX> P0;
+    WavePath wp;
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
+      if (NOISY)
+        wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
+                                             need_keys ? sim_keys : nullptr);
+      else
+        wp = az_wave_chase_lean(ws, h, j, d.max_depth, active);
+      AZ_SIM_STAMP(1);
       if (leader) {
-        depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, cs, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
-        AZ_SIM_STAMP(1);
-        const int parent = cs.hdr[2], action = cs.hdr[3];
+        depth_sum += wp.dep;
+        const WaveLeaf wl = az_wave_leaf(ws, wp.dep, sim);
+        EnvState st;
         if (emb) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) st.s[i] = emb[parent * 5 + i];
-          st.time = (int32_t)az_f2u(emb[parent * 5 + 4]);
+          for (int i = 0; i < 4; ++i) st.s[i] = emb[wl.parent * 5 + i];
+          st.time = (int32_t)az_f2u(emb[wl.parent * 5 + 4]);
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
-          st.time = l.et[parent];
+          for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)wl.parent * 4 + i];
+          st.time = l.et[wl.parent];
         }
         EnvOut o;
         float reward, discount;
-        az_model_env_step(md, st, action, o, reward, discount);
+        az_model_env_step(md, st, wl.action, o, reward, discount);
         if (emb) {
-          const int nn = cs.hdr[1];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) emb[nn * 5 + i] = st.s[i];
-          emb[nn * 5 + 4] = az_u2f((uint32_t)st.time);
+          for (int i = 0; i < 4; ++i) emb[wl.node * 5 + i] = st.s[i];
+          emb[wl.node * 5 + 4] = az_u2f((uint32_t)st.time);
         }
-        cs.hdr[4] = (int32_t)az_f2u(reward);
-        cs.hdr[5] = (int32_t)az_f2u(discount);
+        // the caller's copy of the new node's environment state
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
+        l.et[wl.node] = st.time;
+        ws.hdr[4] = (int32_t)az_f2u(reward);
+        ws.hdr[5] = (int32_t)az_f2u(discount);
         az_store_obs(md, s, ln, o.obs);
       }
-      // The first unit's weights are requested here: the waves without leader threads get
-      // here at once, so their weights arrive while the leaders walk the tree and step the
-      // environment, and the leaders' wave is not held up behind everybody's requests.
-      // The weight registers are not kept across the update below, which needs them.
+      // The path is known now, and the rows the update will need depend on the path only: when a
+      // row fits in a few registers its loads are issued before the networks run, so that
+      // their latency hides behind the MLPs.
+      if (kPrefetch) az_wave_load<AMAX, KMAX>(l, ws, active, j, wp.dep, sim, P0);
+      // The first unit's weights are requested before the barrier, so that they arrive while
+      // the slower waves still walk their trees.  The weight registers are not kept across
+      // the update below, which needs them.
       az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
-      // The path is known now, and the rows the update will need depend on the path only:
-      // gather the path's edge rewards and (when a row fits in a few registers) issue
-      // the row loads before the networks run, so that their latency hides behind the MLPs.
-      dep = cs.hdr[0];
-      newn = cs.hdr[1];
-      if (active && !borrow) az_coop_fill_edges(cs, j, dep);
-      if (kPrefetch && active && j <= dep) az_coop_load<AMAX, KMAX>(l, cs, j, dep, newn, P0);
     }
     az_forward_tile<AZ_MLP_WAVES, true, false>(md, s, wave, lane, regs);
     AZ_SIM_STAMP(4);
-    if (borrow) {  // the activation buffers are free now
-      if (active) az_coop_fill_edges(cs, j, dep);
-      __syncthreads();
-    }
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
-      const int maxdep = az_coop_max_depth(tree_lds, S, borrow != 0);
-      const int parent = cs.hdr[2], action = cs.hdr[3];
-      const float reward = az_u2f((uint32_t)cs.hdr[4]), discount = az_u2f((uint32_t)cs.hdr[5]);
-      if (leader) {
-        if (emb) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = emb[newn * 5 + i];
-          l.et[newn] = (int32_t)az_f2u(emb[newn * 5 + 4]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) l.es[(size_t)newn * 4 + i] = st.s[i];
-          l.et[newn] = st.time;
-        }
-      }
-      for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
-        const int p = j + it * AZ_GROUP;
-        const bool mine = active && p <= dep;
-        CoopPos<AMAX, KMAX> P;
-        if (kPrefetch && it == 0) {
-          P = P0;  // loaded before any of this simulation's updates: no barrier needed
-        } else {
-          if (mine) az_coop_load<AMAX, KMAX>(l, cs, p, dep, newn, P);
-          __syncthreads();  // every load of the iteration before any of its updates
-        }
-        AZ_SIM_STAMP(6 + 3 * (it < 2 ? it : 2));
-        if (mine)
-          az_coop_apply<AMAX, KMAX, NOISY>(c, l, cs, b, p, dep, newn, parent, action,
-                                    s.logits + ln * AZ_MAX_ACTIONS, s.value + ln * AZ_MAX_ATOMS,
-                                    reward, discount, P);
-        __syncthreads();
-        AZ_SIM_STAMP(7 + 3 * (it < 2 ? it : 2));
-      }
+      const float reward = az_u2f((uint32_t)ws.hdr[4]), discount = az_u2f((uint32_t)ws.hdr[5]);
+      az_wave_update<AMAX, KMAX, NOISY>(c, l, ws, active, h, j, sim, wp, s.logits + ln * AZ_MAX_ACTIONS,
+                                        s.value + ln * AZ_MAX_ATOMS, reward, discount,
+                                        kPrefetch ? &P0 : nullptr);
+      AZ_SIM_STAMP(5);
     }
   }
   az_add_depth(sum_depth, (long long)depth_sum);
@@ -466,22 +436,18 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
                    d->K, md.A, md.K);
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   SearchCtx c{*d, *in};
-  // borrowed storage for the path's edge values: only when the plain layout does not fit
-  // and the activation buffers are large enough (2 * S floats per lane)
-  const bool can_borrow = d->S <= az_act_stride(md.pol_kp) + az_act_stride(md.val_kp);
-  const int borrow = !az_coop_applicable(d, lds, false) && can_borrow && az_coop_applicable(d, lds, true);
-  if (borrow || az_coop_applicable(d, lds, false)) {
-    size_t lds2 = lds + (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrow != 0) * 4 + (size_t)2 * d->S * 4;
+  if (az_coop_applicable(d, lds, false)) {
+    size_t lds2 = lds + ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)2 * d->S) * 4;
     const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
     const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
     if (emb_in_lds) lds2 += emb_bytes;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
         const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-        auto kern = noisy ? k_search_fused_coop<AMAX, KMAX, true> : k_search_fused_coop<AMAX, KMAX, false>;
+        auto kern = noisy ? k_search_fused_wave<AMAX, KMAX, true> : k_search_fused_wave<AMAX, KMAX, false>;
         if (int rc = az_set_lds((const void*)kern, lds2)) return rc;
         kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
-               (hipStream_t)stream>>>(c, *t, md, emb_in_lds, borrow,
+               (hipStream_t)stream>>>(c, *t, md, emb_in_lds,
                                       reinterpret_cast<unsigned long long*>(sum_depth));
         AZ_LAUNCH_CHECK();
         return AZ_OK;

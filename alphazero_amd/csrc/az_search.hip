@@ -9,10 +9,8 @@
 #include <string>
 #include <vector>
 
-#include <cstdlib>
-
 #include "az_host.h"
-#include "az_coop.h"
+#include "az_wave.h"
 
 // ---------------------------------------------------------------------------
 // tree init: one thread per (lane, node)
@@ -99,11 +97,11 @@ AZ_UNROLL_K
 }
 
 #ifdef AZ_STAMP
-// Diagnostic build only: cycle stamps of the leader of lane 0 in workgroup 0, one row per simulation.
+// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation.
 __device__ long long az_tree_stamps[64][8];
-#define AZ_TREE_STAMP(k)                                                                                   \
-  do {                                                                                                     \
-    if (blockIdx.x == 0 && j == 0 && ln == 0 && sim < 64) az_tree_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
+#define AZ_TREE_STAMP(k)                                                                              \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && tid == 0 && sim < 64) az_tree_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 extern "C" int az_debug_read_tree_stamps(long long* host_out) {
   AZ_HIP(hipDeviceSynchronize());
@@ -116,40 +114,33 @@ extern "C" int az_debug_read_tree_stamps(long long* host_out) {
   } while (0)
 #endif
 
-// The same search in the cooperative form (az_coop.h): 16 lanes per workgroup, 32
-// threads per lane, cached selections and the path in LDS.
+// The same search in the cooperative form (az_wave.h): 16 lanes per workgroup, two lanes per
+// wave, 32 threads per lane; cached selections and the path in LDS; no workgroup barrier inside
+// the simulation loop.
 // TREE_LDS: the statistics arrays are staged in LDS for the whole search (a template parameter
 // so that the compiler sees LDS addresses and emits LDS instructions, not generic ones).
 template <int AMAX, int KMAX, bool NOISY, bool TREE_LDS>
-__global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_coop_injected(
+__global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_injected(
     SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
   constexpr int tree_in_lds = TREE_LDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const az_search_desc& d = c.d;
   const int A = d.A, K = d.K, S = d.S;
-  // position-major: a wave holds 4 consecutive path positions of all 16 lanes, so waves
-  // beyond the path's depth do nothing and the 16 lane leaders (position 0) share one wave --
-  // the last one: the root's selection rule and the interior one are different code, and this
-  // way they run in different waves at the same time
-  const int tid = threadIdx.x, ln = tid & (AZ_WG_LANES - 1), j = (tid / AZ_WG_LANES + 1) & (AZ_GROUP - 1);
-  const int b = blockIdx.x * AZ_WG_LANES + ln;
+  const int tid = threadIdx.x, ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
+  const int b0 = blockIdx.x * AZ_WG_LANES, b = b0 + ln;
   const bool active = b < d.B;
-  CoopLds s(lds, ln, S);
-  // with room in LDS the lanes' statistics arrays are staged there for the whole search
-  const int b0 = blockIdx.x * AZ_WG_LANES;
+  WaveLds s(lds, ln, S);
+  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(lds + AZ_WG_LANES * WaveLds::lane_words(S));
   const int lanes_here = d.B - b0 < AZ_WG_LANES ? d.B - b0 : AZ_WG_LANES;
-  TreeLds tl(lds + AZ_WG_LANES * az_coop_lane_words(S) + 2 * S, S + 1, A, K);
+  TreeLds tl(reinterpret_cast<float*>(sim_keys + 2 * S), S + 1, A, K);
   if (tree_in_lds) tl.copy(t, b0, lanes_here, true, tid, blockDim.x);
   const az_tree tv = tree_in_lds ? tl.view() : t;
   Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
-  if (tree_in_lds) __syncthreads();
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
-  uint32_t* sim_keys = reinterpret_cast<uint32_t*>(lds + AZ_WG_LANES * az_coop_lane_words(S));
-  if (need_keys) az_coop_sim_keys(d, sim_keys, tid, blockDim.x);
-  if (j == 0) {
-    s.hdr[0] = -1;
-    if (active) az_coop_init<AMAX, KMAX, NOISY>(c, l, s, b);
-  }
+  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
+  if (j == 0) s.selx[0] = 0;
+  __syncthreads();
+  if (j == 0 && active) az_wave_init<AMAX, KMAX, NOISY>(c, l, s, b);
   __syncthreads();
   long long depth_sum = 0;
   float ev_logits[AMAX], ev_value[KMAX], reward, discount;
@@ -167,12 +158,13 @@ AZ_UNROLL_K
   }
   for (int sim = 0; sim < S; ++sim) {
     AZ_TREE_STAMP(0);
-    if (NOISY) {
-      if (j == 0 && active)
-        depth_sum += az_coop_chase<AMAX, KMAX, NOISY>(c, l, s, b, sim, d.max_depth, need_keys ? sim_keys : nullptr);
-    } else if (j == 0) {  // the whole leader wave walks together (inactive lanes under a false predicate)
-      depth_sum += az_coop_chase_lean(s, sim, d.max_depth, active);
-    }
+    WavePath wp;
+    if (NOISY)
+      wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
+                                           need_keys ? sim_keys : nullptr);
+    else
+      wp = az_wave_chase_lean(s, h, j, d.max_depth, active);
+    if (j == 0) depth_sum += wp.dep;
     AZ_TREE_STAMP(1);
     // the recurrent_fn outputs of the NEXT simulation of this lane are requested here, a whole
     // simulation before the update that consumes them, so that their latency is never waited for
@@ -188,28 +180,9 @@ AZ_UNROLL_K
       nx_reward = inj.reward[e];
       nx_discount = inj.discount[e];
     }
-    az_coop_lds_barrier();  // the walk's results live in LDS; the loads above stay in flight
+    az_wave_update<AMAX, KMAX, NOISY>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
+                                      discount);
     AZ_TREE_STAMP(2);
-    const int maxdep = az_coop_max_depth(lds, S);
-    const int dep = s.hdr[0], newn = s.hdr[1], parent = s.hdr[2], action = s.hdr[3];
-    if (active) az_coop_fill_edges(s, j, dep);
-    for (int it = 0; it * AZ_GROUP <= maxdep; ++it) {
-      const int p = j + it * AZ_GROUP;
-      const bool mine = active && p <= dep;
-      CoopPos<AMAX, KMAX> P;
-      if (mine) az_coop_load<AMAX, KMAX>(l, s, p, dep, newn, P);
-      if (it == 0) AZ_TREE_STAMP(3);
-      // with the statistics in LDS nothing the other threads need is in global memory, and a
-      // barrier that only publishes LDS keeps the prefetch above in flight
-      if (TREE_LDS) az_coop_lds_barrier(); else __syncthreads();
-      if (it == 0) AZ_TREE_STAMP(4);
-      if (mine)
-        az_coop_apply<AMAX, KMAX, NOISY>(c, l, s, b, p, dep, newn, parent, action, ev_logits, ev_value,
-                                  reward, discount, P);
-      if (it == 0) AZ_TREE_STAMP(5);
-      if (TREE_LDS) az_coop_lds_barrier(); else __syncthreads();
-      if (it == 0) AZ_TREE_STAMP(6);
-    }
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a) ev_logits[a] = nx_logits[a];
 AZ_UNROLL_K
@@ -224,16 +197,18 @@ AZ_UNROLL_K
   az_add_depth(sum_depth, depth_sum);
 }
 
-// Whether the cooperative form applies (see az_coop.h) and fits in LDS next to
-// `extra_lds_bytes` of other use.  AZ_FORCE_LITERAL=1 in the environment selects the
-// literal kernels (used to cross-check the two forms).
+// LDS bytes of the cooperative form's own state (cached selections, path, root inputs, keys).
+static size_t az_wave_lds_bytes(const az_search_desc* d) {
+  return ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)2 * d->S) * 4;
+}
+
+// Whether the cooperative form applies (see az_wave.h) and fits in LDS next to
+// `extra_lds_bytes` of other use.
 bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool borrowed) {
-  const char* force = getenv("AZ_FORCE_LITERAL");
-  if (force && force[0] == '1') return false;
+  if (d->kernel_form == 1) return false;  // the caller asked for the literal kernels
   if (d->A > 8 || d->K > 8 || d->S + 1 > 65535) return false;
-  const size_t bytes = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S, borrowed) * 4 + extra_lds_bytes +
-                       (size_t)2 * d->S * 4;  // + the per-simulation keys
-  return bytes <= 160 * 1024;
+  (void)borrowed;
+  return az_wave_lds_bytes(d) + extra_lds_bytes <= 160 * 1024;
 }
 
 extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
@@ -245,17 +220,17 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, 0, false)) {
-    size_t lds = (size_t)AZ_WG_LANES * az_coop_lane_words(d->S) * 4 + (size_t)2 * d->S * 4;
+    size_t lds = az_wave_lds_bytes(d);
     const size_t tree_bytes = TreeLds::words(d->S + 1, d->A, d->K) * 4;
     const int tree_in_lds = lds + tree_bytes <= 160 * 1024;
     if (tree_in_lds) lds += tree_bytes;
     return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
       if constexpr (AMAX <= 8 && KMAX <= 8) {
         const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-        auto kern = noisy ? (tree_in_lds ? k_search_coop_injected<AMAX, KMAX, true, true>
-                                         : k_search_coop_injected<AMAX, KMAX, true, false>)
-                          : (tree_in_lds ? k_search_coop_injected<AMAX, KMAX, false, true>
-                                         : k_search_coop_injected<AMAX, KMAX, false, false>);
+        auto kern = noisy ? (tree_in_lds ? k_search_wave_injected<AMAX, KMAX, true, true>
+                                         : k_search_wave_injected<AMAX, KMAX, true, false>)
+                          : (tree_in_lds ? k_search_wave_injected<AMAX, KMAX, false, true>
+                                         : k_search_wave_injected<AMAX, KMAX, false, false>);
         if (lds > 48 * 1024)
           AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));

@@ -1,0 +1,639 @@
+// az_wave.h -- cooperative form of the tree search: 32 threads per lane, two lanes per wave,
+// and nothing inside a simulation that crosses a wave.
+//
+// The literal search (az_device.h) walks root -> leaf re-evaluating the selection rule at every
+// level and then walks leaf -> root again for the backup.  The selection at a node depends only
+// on that node's own statistics, and those change only when the node lies on a backup path.
+// So this form keeps, per node, the action the rule currently selects together with the child it
+// leads to (`selx`, in LDS), and a simulation becomes
+//   1. chase   : follow `selx` from the root -- one dependent LDS read per level -- and record
+//                the path (search.py:127-187);
+//   2. evaluate: the caller's recurrent_fn (injected arrays, or environment + networks);
+//   3. update  : the 32 threads of the lane take one path position each (deeper paths take
+//                several passes, deepest block first): load the node's own row, run the backup's
+//                value chain (search.py:265-286) as a systolic pass over the wave's lanes --
+//                position p+1 hands reward + discount * value to position p through a
+//                one-lane DPP shift -- apply expand / backward to the row, and re-evaluate the
+//                selection rule on the updated row.
+// A thread reads no row but its own: the updated value of its child arrives by the same DPP
+// shift.  Both lanes of a wave and all their positions live in that wave, so the simulation
+// loop needs no workgroup barrier; LDS accesses of one wave execute in program order.
+// Every floating-point operation is the same, on the same operands and in the same order, as in
+// the literal form, so the resulting tree is bit-identical.
+//
+// Per-visit randomness: the PUCT rules add 1e-7 * uniform noise to break ties.  A cached pick is
+// marked ambiguous when that noise could change it (the top two scores closer than the noise),
+// and the chase then evaluates that node exactly, with the visit's own noise, as the literal
+// form does; everywhere else the noise cannot matter.  The kernels are instantiated twice
+// (NOISY): the form without per-visit noise (Gumbel, or PUCT with the noise disabled) carries
+// none of that code.
+//
+// Applicability: A <= 8, K <= 8 (vectors in registers), N <= 65535 (16-bit node codes).
+#ifndef AZ_WAVE_H_
+#define AZ_WAVE_H_
+
+#include "az_device.h"
+
+#define AZ_POS 32          // path positions (threads) per lane and pass
+#define AZ_WG_LANES 16     // lanes per workgroup (8 waves x 2 lanes)
+#define AZ_TREE_THREADS (AZ_POS * AZ_WG_LANES)
+#define AZ_SEL_AMBIG (1 << 30)
+
+// Compiler-level ordering point between LDS / memory accesses of different threads of ONE wave
+// (the hardware already executes a wave's memory instructions in program order).
+AZ_DEV void az_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Value of wave lane i + 1 (0 for lane 63): one VALU instruction (DPP wave_shl:1).
+AZ_DEV float az_from_next_lane(float x) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+
+// Per-lane words of LDS.  selx[k] is the cached selection of node k - 1:
+// (action << 16) | (child + 1) [| AZ_SEL_AMBIG]; selx[0] = 0 is what a finished walk keeps reading.
+// path[t] is the selection word the walk read at level t.
+struct WaveLds {
+  int32_t* selx;      // [S + 2]
+  int32_t* path;      // [S + 4]
+  float* root_g;      // [8] the root's Gumbel noise
+  float* root_inv;    // [8] the root's invalid-action mask
+  int32_t* hdr;       // [8] 4, 5: reward / discount bits of the evaluation; 7: table row
+  int32_t* root_tab;  // [S] the row of the considered-visits table this lane uses
+  __host__ __device__ static inline int lane_words(int S) { return 3 * S + 32; }
+  AZ_DEV WaveLds(float* base, int lane, int S) {
+    float* p = base + (size_t)lane * lane_words(S);
+    selx = reinterpret_cast<int32_t*>(p);
+    path = selx + (S + 2);
+    root_g = p + 2 * S + 6;
+    root_inv = root_g + 8;
+    hdr = reinterpret_cast<int32_t*>(root_inv + 8);
+    root_tab = hdr + 8;
+  }
+  // Copies of the root-only selection inputs (filled by az_wave_init): the root is re-selected
+  // every simulation.
+  AZ_DEV RootCache root_cache(const SearchCtx& c) const {
+    RootCache rc;
+    rc.gumbel = root_g;
+    rc.invalid = root_inv;
+    rc.has_invalid = c.in.invalid_actions != nullptr;
+    rc.table_row = root_tab;
+    rc.table_nc = hdr[7];
+    return rc;
+  }
+};
+
+// The statistics arrays of a workgroup's lanes staged in LDS for the whole search (when they
+// fit): the search then touches HBM twice per array -- one coalesced read of the fresh tree and
+// one coalesced write of the finished one (the 16 lanes of a workgroup are contiguous in every
+// [B, N, ...] array) -- instead of a cache line per node visit.  `view()` is an az_tree over the
+// copies, indexed by the lane's position in the workgroup.
+struct TreeLds {
+  int32_t *nv, *par, *afp, *cidx, *cvis;
+  float *raw, *nval, *clog, *crew, *cdisc, *cval;
+  int N, A, K;
+  __host__ __device__ static inline size_t words(int N, int A, int K) {
+    return (size_t)AZ_WG_LANES * N * (3 + 2 * K + A * (5 + K));
+  }
+  AZ_DEV TreeLds(float* base, int N_, int A_, int K_) : N(N_), A(A_), K(K_) {
+    const int L = AZ_WG_LANES * N;
+    int32_t* ip = reinterpret_cast<int32_t*>(base);
+    nv = ip;
+    par = ip + L;
+    afp = ip + 2 * L;
+    cidx = ip + 3 * L;
+    cvis = cidx + L * A;
+    float* fp = reinterpret_cast<float*>(cvis + L * A);
+    raw = fp;
+    nval = raw + L * K;
+    clog = nval + L * K;
+    crew = clog + L * A;
+    cdisc = crew + L * A;
+    cval = cdisc + L * A;
+  }
+  AZ_DEV az_tree view() const {
+    az_tree v{};
+    v.node_visits = nv;
+    v.parents = par;
+    v.action_from_parent = afp;
+    v.children_index = cidx;
+    v.children_visits = cvis;
+    v.raw_values = raw;
+    v.node_values = nval;
+    v.children_prior_logits = clog;
+    v.children_rewards = crew;
+    v.children_discounts = cdisc;
+    v.children_values = cval;
+    v.emb_state = nullptr;
+    v.emb_time = nullptr;
+    return v;
+  }
+  // copies the lanes [b0, b0 + lanes) between the global tree and LDS (workgroup-wide)
+  AZ_DEV void copy(const az_tree& t, int b0, int lanes, bool to_lds, int tid, int nthreads) const {
+    const size_t o = (size_t)b0 * N;
+    const int n1 = lanes * N, nA = n1 * A, nK = n1 * K, nAK = nA * K;
+#define AZ_TL_COPY(lds_arr, glob_arr, off, count)                          \
+  for (int i = tid; i < (count); i += nthreads) {                          \
+    if (to_lds)                                                            \
+      lds_arr[i] = (glob_arr)[(off) + i];                                  \
+    else                                                                   \
+      (glob_arr)[(off) + i] = lds_arr[i];                                  \
+  }
+    AZ_TL_COPY(nv, t.node_visits, o, n1)
+    AZ_TL_COPY(par, t.parents, o, n1)
+    AZ_TL_COPY(afp, t.action_from_parent, o, n1)
+    AZ_TL_COPY(cidx, t.children_index, o * A, nA)
+    AZ_TL_COPY(cvis, t.children_visits, o * A, nA)
+    AZ_TL_COPY(raw, t.raw_values, o * K, nK)
+    AZ_TL_COPY(nval, t.node_values, o * K, nK)
+    AZ_TL_COPY(clog, t.children_prior_logits, o * A, nA)
+    AZ_TL_COPY(crew, t.children_rewards, o * A, nA)
+    AZ_TL_COPY(cdisc, t.children_discounts, o * A, nA)
+    AZ_TL_COPY(cval, t.children_values, o * A * K, nAK)
+#undef AZ_TL_COPY
+  }
+};
+
+// Every per-node word of one node, in registers.
+template <int AMAX, int KMAX>
+struct FullRow {
+  int32_t nv;
+  int32_t cidx[AMAX], vis[AMAX];
+  float logits[AMAX], rew[AMAX], disc[AMAX];
+  float cval[AMAX][KMAX];
+  float raw[KMAX], nval[KMAX];
+};
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_load_full_row(const Lane<AMAX, KMAX>& l, int node, FullRow<AMAX, KMAX>& r) {
+  const int A = l.A, K = l.K;
+  r.nv = l.nv[node];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      r.cidx[a] = l.cidx[node * A + a];
+      r.vis[a] = l.cvis[node * A + a];
+      r.logits[a] = l.clog[node * A + a];
+      r.rew[a] = l.crew[node * A + a];
+      r.disc[a] = l.cdisc[node * A + a];
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) r.cval[a][k] = l.cval[((size_t)node * A + a) * K + k];
+    }
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k)
+    if (k < K) {
+      r.raw[k] = l.raw[(size_t)node * K + k];
+      r.nval[k] = l.nval[(size_t)node * K + k];
+    }
+}
+
+// The selection inputs of a row held in registers; same arithmetic as az_load_row (a mean over
+// one atom divides by 1.0f, which changes no bit and is left out).
+template <int AMAX, int KMAX>
+AZ_DEV void az_node_row(const FullRow<AMAX, KMAX>& f, int A, int K, NodeRow<AMAX>& r) {
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      r.vis[a] = f.vis[a];
+      r.logits[a] = f.logits[a];
+      float s = 0.0f;
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) s = s + (f.rew[a] + f.disc[a] * f.cval[a][k]);
+      r.q[a] = KMAX == 1 ? s : s / (float)K;
+    }
+  float sv = 0.0f, sr = 0.0f;
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k)
+    if (k < K) {
+      sv = sv + f.nval[k];
+      sr = sr + f.raw[k];
+    }
+  r.vmean = KMAX == 1 ? sv : sv / (float)K;
+  r.rawmean = KMAX == 1 ? sr : sr / (float)K;
+  r.node_visit = f.nv;
+}
+
+// The action the search's selection rule picks at a node (root: depth 0), evaluated WITHOUT
+// per-visit noise.  Root and interior positions share a wave, so the two Gumbel rules are
+// written as one qtransform followed by two short tails instead of two whole rules.
+// `ambiguous` tells whether the PUCT tie-break noise (1e-7 * u, u in [0, 1)) could change the
+// pick: it cannot when the best score leads every other one by more than the noise plus the
+// rounding of the additions; otherwise the chase re-evaluates the node with the visit's actual
+// noise (az_wave_exact_select).
+template <int AMAX, bool NOISY>
+AZ_DEV int az_select_cached(const SearchCtx& c, const RootCache& rc, int A, bool root,
+                            const NodeRow<AMAX>& r, bool& ambiguous) {
+  ambiguous = false;
+  if (c.d.variant == AZ_VARIANT_GUMBEL) {
+    float cq[AMAX];
+    az_qtransform<AMAX>(c.d, A, r, cq);
+    int best = az_gumbel_interior_tail<AMAX>(A, r, cq);
+    if (root) best = az_gumbel_root_tail<AMAX>(c, A, r, cq, rc);
+    return best;
+  }
+  float score[AMAX], noise[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a) noise[a] = 1e-7f * 0.0f;
+  az_puct_scores<AMAX>(c, A, r, score);
+  const int best = az_puct_argmax<AMAX>(A, root ? 0 : 1, score, noise, rc);
+  if (NOISY && c.d.noise_mode != AZ_NOISE_ZERO) {
+    const bool use_mask = root && rc.has_invalid;
+    float bs = 0.0f;
+    bool best_masked = false;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a == best) {
+        bs = score[a];
+        best_masked = use_mask && rc.invalid[a] != 0.0f;
+      }
+    if (best_masked || !(bs == bs)) ambiguous = true;  // everything masked, or NaN: let the exact rule decide
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A && a != best && !(use_mask && rc.invalid[a] != 0.0f)) {
+        const float x = score[a];
+        float m = bs < 0.0f ? -bs : bs;
+        const float ax = x < 0.0f ? -x : x;
+        m = ax > m ? ax : m;
+        m = m > 1.0f ? m : 1.0f;
+        if (!(bs - x > 4e-7f * m)) ambiguous = true;
+      }
+  }
+  return best;
+}
+
+AZ_DEV int32_t az_pack_sel(int action, int child, bool ambiguous = false) {
+  return (action << 16) | (child + 1) | (ambiguous ? AZ_SEL_AMBIG : 0);
+}
+
+// The selection at `node` with the tie-break noise of visit (sim, depth), as the literal search
+// evaluates it (az_simulate_lane).  (k0, k1) is the lane's simulate key advanced to `key_depth`
+// levels; it is advanced further as needed.
+template <int AMAX, int KMAX>
+AZ_DEV int az_wave_exact_select(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const RootCache& rc,
+                                int b, int sim, int node, int depth, uint32_t& k0, uint32_t& k1,
+                                int& key_depth, int& child) {
+  const int A = l.A;
+  NodeRow<AMAX> r;
+  az_load_row<AMAX, KMAX>(l, node, r);
+  if (c.d.noise_mode == AZ_NOISE_THREEFRY)
+    for (; key_depth < depth; ++key_depth) {
+      uint32_t n0, n1;
+      az_key_split(k0, k1, 0u, &n0, &n1);
+      k0 = n0;
+      k1 = n1;
+    }
+  float noise[AMAX];
+  az_puct_noise<AMAX>(c, A, b, sim, depth, k0, k1, noise);
+  key_depth = depth + 1;
+  const int act = az_select_puct<AMAX>(c, A, depth, r, noise, rc);
+  child = l.cidx[node * A + act];
+  return act;
+}
+
+// Before the first simulation (one thread per lane): the root-only inputs into LDS and the
+// selection at the root of the fresh tree.
+template <int AMAX, int KMAX, bool NOISY>
+AZ_DEV void az_wave_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, int b) {
+  const int A = l.A;
+  for (int a = 0; a < A; ++a) {
+    s.root_g[a] = c.in.root_gumbel ? c.in.root_gumbel[(size_t)b * A + a] : 0.0f;
+    s.root_inv[a] = c.in.invalid_actions ? c.in.invalid_actions[(size_t)b * A + a] : 0.0f;
+  }
+  s.hdr[7] = -1;
+  if (c.d.variant == AZ_VARIANT_GUMBEL && c.in.table) {
+    float nvalid = 0.0f;
+    for (int a = 0; a < A; ++a) nvalid = nvalid + (1.0f - s.root_inv[a]);
+    const int32_t nc = az_num_considered(c.d, nvalid);
+    for (int i = 0; i < c.d.S; ++i) s.root_tab[i] = c.in.table[(size_t)nc * c.d.S + i];
+    s.hdr[7] = nc;
+  }
+  FullRow<AMAX, KMAX> f;
+  NodeRow<AMAX> r;
+  az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
+  az_node_row<AMAX, KMAX>(f, A, l.K, r);
+  bool ambiguous;
+  const int a = az_select_cached<AMAX, NOISY>(c, s.root_cache(c), A, true, r, ambiguous);
+  int child = AZ_UNVISITED;
+AZ_UNROLL_A
+  for (int i = 0; i < AZ_TRIP_A; ++i)
+    if (i == a) child = f.cidx[i];
+  s.selx[AZ_ROOT + 1] = az_pack_sel(a, child, ambiguous);
+}
+
+// The simulate keys of all S simulations into `sim_keys` ([S][2] words of LDS): the rng chain
+// rng, simulate_key, expand_key = split(rng, 3) (search.py:90) is sequential, so one thread walks
+// it and the others derive their simulation's key from it.  Workgroup-wide call (barriers).
+AZ_DEV void az_wave_sim_keys(const az_search_desc& d, uint32_t* sim_keys, int tid, int nthreads) {
+  if (tid == 0) {
+    uint32_t r0 = d.key[0], r1 = d.key[1];
+    for (int i = 0; i < d.S; ++i) {
+      sim_keys[2 * i] = r0;
+      sim_keys[2 * i + 1] = r1;
+      uint32_t n0, n1;
+      az_key_split(r0, r1, 0u, &n0, &n1);
+      r0 = n0;
+      r1 = n1;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < d.S; i += nthreads) {
+    uint32_t s0, s1;
+    az_key_split(sim_keys[2 * i], sim_keys[2 * i + 1], 1u, &s0, &s1);
+    sim_keys[2 * i] = s0;
+    sim_keys[2 * i + 1] = s1;
+  }
+  __syncthreads();
+}
+
+// What the walk leaves behind for the update, the same in every thread of a lane.
+struct WavePath {
+  int dep;      // levels walked = depth of the evaluated node (0: inactive lane)
+  int dep_max;  // the larger `dep` of the wave's two lanes (wave-uniform)
+};
+
+// Depth of the recorded path of both lanes of the wave after a walk of `t_exit` levels
+// (entries [0, t_exit) of `path` are this simulation's; the walk wrote 0 past a lane's end).
+AZ_DEV WavePath az_wave_path_depth(const WaveLds& s, int h, int j, int t_exit, int max_depth,
+                                   bool active) {
+  int d0 = 0, d1 = 0;
+  for (int base = 0; base < t_exit; base += AZ_POS) {
+    // position p lies on the path iff the walk reached it: p == 0, or level p - 1 led to a
+    // visited child and the depth cap (search.py:183) allowed another level
+    const int p = base + j;
+    bool on = active && p < t_exit;
+    if (on && p > 0) on = (s.path[p - 1] & 0xffff) != 0 && p < max_depth;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+    d0 += __builtin_popcount((unsigned)m);
+    d1 += __builtin_popcount((unsigned)(m >> 32));
+  }
+  WavePath w;
+  w.dep = h ? d1 : d0;
+  w.dep_max = d0 > d1 ? d0 : d1;
+  return w;
+}
+
+// Step 1 for the rules without per-visit noise: thread 0 of each lane follows the cached
+// selections from the root and records the selection word of every level.  The loop carries the
+// node code only -- a wave alone on its SIMD issues an instruction every four cycles or so, so a
+// level costs its instruction count as much as the LDS round trip -- and ends on one scalar test
+// per four levels; a lane whose walk has ended keeps reading selx[0] = 0 meanwhile.
+AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int max_depth, bool active) {
+  int t = 0;
+  int k = active && j == 0 ? 1 : 0;
+  while (__builtin_amdgcn_ballot_w64(k != 0) != 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t e = s.selx[k];
+      if (j == 0) s.path[t] = e;
+      t += 1;
+      k = t < max_depth ? (e & 0xffff) : 0;
+    }
+  }
+  az_wave_sync();
+  return az_wave_path_depth(s, h, j, t, max_depth, active);
+}
+
+// The same walk for the PUCT rules with per-visit noise: a cached pick that the noise could
+// change is re-evaluated with the visit's own noise.  `sim_keys` ([S][2] words, or null): the
+// per-simulation simulate keys (search.py:90).
+template <int AMAX, int KMAX>
+AZ_DEV WavePath az_wave_chase_noisy(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s,
+                                    int b, int h, int j, int sim, int max_depth, bool active,
+                                    const uint32_t* sim_keys) {
+  int dep = 0;
+  if (active && j == 0) {
+    const RootCache rc = s.root_cache(c);
+    int node = AZ_ROOT;
+    uint32_t k0 = 0u, k1 = 0u;
+    int key_depth = -1;  // -1: the lane's key of this simulation has not been derived yet
+    for (;;) {
+      int32_t e = s.selx[node + 1];
+      if (e & AZ_SEL_AMBIG) {
+        if (key_depth < 0) {
+          if (sim_keys) az_key_split(sim_keys[2 * sim], sim_keys[2 * sim + 1], (uint32_t)b, &k0, &k1);
+          key_depth = 0;
+        }
+        int child;
+        const int act = az_wave_exact_select<AMAX, KMAX>(c, l, rc, b, sim, node, dep, k0, k1, key_depth, child);
+        e = az_pack_sel(act, child);
+      }
+      s.path[dep] = e;
+      dep += 1;
+      const int nxt = (e & 0xffff) - 1;
+      if (nxt < 0 || dep >= max_depth) break;
+      node = nxt;
+    }
+  }
+  az_wave_sync();
+  const int d0 = __builtin_amdgcn_readlane(dep, 0), d1 = __builtin_amdgcn_readlane(dep, 32);
+  WavePath w;
+  w.dep = h ? d1 : d0;
+  w.dep_max = d0 > d1 ? d0 : d1;
+  return w;
+}
+
+// The node the evaluation expands: parent = the last node of the path, action = the action
+// taken there, node = the child it leads to, or node `sim + 1` when that edge is unvisited
+// (search.py:97-99).  Valid in every thread of an active lane.
+struct WaveLeaf {
+  int parent, action, node;
+};
+AZ_DEV WaveLeaf az_wave_leaf(const WaveLds& s, int dep, int sim) {
+  WaveLeaf w;
+  const int32_t e = s.path[dep - 1];
+  const int kc = e & 0xffff;
+  w.action = (e >> 16) & 0xff;
+  w.node = kc == 0 ? sim + 1 : kc - 1;
+  w.parent = dep > 1 ? (s.path[dep - 2] & 0xffff) - 1 : AZ_ROOT;
+  return w;
+}
+
+// What path position p of a lane works on: its node, the action the path takes there, and the
+// node's row.  (Positions past the path's end, and inactive lanes, get an all-zero row.)
+template <int AMAX, int KMAX>
+struct WaveRow {
+  FullRow<AMAX, KMAX> f;
+  int node, act;
+};
+
+template <int AMAX, int KMAX>
+AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active, int p, int dep,
+                         int sim, WaveRow<AMAX, KMAX>& w) {
+  w.node = AZ_ROOT;
+  w.act = 0;
+  w.f = FullRow<AMAX, KMAX>{};
+  if (active && p <= dep) {
+    const int kc = p > 0 ? (s.path[p - 1] & 0xffff) : 1;
+    if (p == dep) {
+      w.node = kc == 0 ? sim + 1 : kc - 1;  // search.py:97-99
+    } else {
+      w.node = kc - 1;
+      w.act = (s.path[p] >> 16) & 0xff;
+    }
+    az_load_full_row<AMAX, KMAX>(l, w.node, w.f);
+  }
+}
+
+// Step 3: expand (search.py:231-244, 304-342) and backward (search.py:265-286) applied to every
+// node of the recorded path plus the evaluated node, and their cached selections refreshed.
+// Position p of the path (0 = root ... dep-1 = parent, dep = the evaluated node) belongs to
+// thread p % 32 of the lane in pass p / 32.  ev_logits [A] / ev_value [K] / reward / discount
+// are the recurrent_fn's outputs for this lane (any address space; read by every thread).
+// `pre` (or null): the rows of pass 0, loaded by az_wave_load ahead of the evaluation.
+template <int AMAX, int KMAX, bool NOISY>
+AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active,
+                           int h, int j, int sim, const WavePath& wp, const float* ev_logits,
+                           const float* ev_value, float reward, float discount,
+                           const WaveRow<AMAX, KMAX>* pre = nullptr) {
+  const int A = l.A, K = l.K;
+  const int dep = wp.dep;
+  const RootCache rc = s.root_cache(c);
+  float carry_x[KMAX], carry_child[KMAX];
+AZ_UNROLL_K
+  for (int k = 0; k < AZ_TRIP_K; ++k) {
+    carry_x[k] = k < K && active ? ev_value[k] : 0.0f;  // backward starts from the evaluated node's value
+    carry_child[k] = 0.0f;
+  }
+  for (int it = wp.dep_max / AZ_POS; it >= 0; --it) {
+    const int p = j + it * AZ_POS;
+    const bool mine = active && p <= dep;
+    const bool leaf = p == dep;
+    WaveRow<AMAX, KMAX> w;
+    if (pre != nullptr && it == 0)
+      w = *pre;
+    else
+      az_wave_load<AMAX, KMAX>(l, s, active, p, dep, sim, w);
+    FullRow<AMAX, KMAX>& f = w.f;
+    const int node = w.node, act = w.act;
+    // the edge from this position's node to the next node of the path
+    float r_p = 0.0f, d_p = 0.0f;
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a == act) {
+        r_p = f.rew[a];
+        d_p = f.disc[a];
+      }
+    if (p == dep - 1) {
+      r_p = reward;
+      d_p = discount;
+    }
+    // backward's value chain, leaf -> root: at step u the thread whose turn it is holds, in x,
+    // the value its child position computed one step earlier (the deepest one starts from the
+    // block's carry-in), computes its own, and every thread hands its result one lane down.
+    const int jstart = dep - 1 - it * AZ_POS < AZ_POS - 1 ? dep - 1 - it * AZ_POS : AZ_POS - 1;
+    const int js_max = wp.dep_max - 1 - it * AZ_POS < AZ_POS - 1 ? wp.dep_max - 1 - it * AZ_POS : AZ_POS - 1;
+    const int myturn = jstart - j;
+    float x[KMAX], lv[KMAX];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k) {
+      x[k] = carry_x[k];
+      lv[k] = 0.0f;
+    }
+    for (int u = 0; u <= js_max; ++u) {
+      const bool turn = u == myturn;
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) {
+          const float y = r_p + d_p * x[k];
+          lv[k] = turn ? y : lv[k];
+          x[k] = az_from_next_lane(y);
+        }
+    }
+    // the node's new value; its child's new value arrives from the next lane
+    const float cnt = (float)f.nv;
+    float nval_new[KMAX], child_new[KMAX];
+AZ_UNROLL_K
+    for (int k = 0; k < AZ_TRIP_K; ++k) {
+      nval_new[k] = 0.0f;
+      if (k < K) nval_new[k] = leaf ? (active ? ev_value[k] : 0.0f) : (f.nval[k] * cnt + lv[k]) / (cnt + 1.0f);
+      child_new[k] = az_from_next_lane(nval_new[k]);
+    }
+    if (wp.dep_max >= AZ_POS) {  // several passes: hand the block's lowest position to the next pass
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k) {
+        if (j == AZ_POS - 1) child_new[k] = carry_child[k];
+        const float lv0 = __shfl(lv[k], 0, AZ_POS), nv0 = __shfl(nval_new[k], 0, AZ_POS);
+        if (jstart >= 0) carry_x[k] = lv0;
+        carry_child[k] = nv0;
+      }
+    }
+    if (mine) {
+      if (leaf) {
+        // the evaluated node (update_tree_node, search.py:304-342)
+        const WaveLeaf wl = az_wave_leaf(s, dep, sim);
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a < A) {
+            f.logits[a] = ev_logits[a];
+            l.clog[node * A + a] = f.logits[a];
+          }
+AZ_UNROLL_K
+        for (int k = 0; k < AZ_TRIP_K; ++k)
+          if (k < K) {
+            f.raw[k] = ev_value[k];
+            f.nval[k] = ev_value[k];
+            l.raw[(size_t)node * K + k] = f.raw[k];
+            l.nval[(size_t)node * K + k] = f.nval[k];
+          }
+        f.nv = f.nv + 1;
+        l.nv[node] = f.nv;
+        l.par[node] = wl.parent;
+        l.afp[node] = wl.action;
+      } else {
+        if (p == dep - 1) {
+          // the edge parent -> evaluated node (search.py:235-241)
+          const int newn = az_wave_leaf(s, dep, sim).node;
+AZ_UNROLL_A
+          for (int a = 0; a < AZ_TRIP_A; ++a)
+            if (a == act) {
+              f.cidx[a] = newn;
+              f.rew[a] = reward;
+              f.disc[a] = discount;
+            }
+          l.cidx[node * A + act] = newn;
+          l.crew[node * A + act] = reward;
+          l.cdisc[node * A + act] = discount;
+        }
+        // backward (search.py:265-286) at this node
+        int32_t newvis = 0;
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a == act) {
+AZ_UNROLL_K
+            for (int k = 0; k < AZ_TRIP_K; ++k)
+              if (k < K) f.cval[a][k] = child_new[k];
+            f.vis[a] = f.vis[a] + 1;
+            newvis = f.vis[a];
+          }
+AZ_UNROLL_K
+        for (int k = 0; k < AZ_TRIP_K; ++k)
+          if (k < K) {
+            f.nval[k] = nval_new[k];
+            l.nval[(size_t)node * K + k] = nval_new[k];
+            l.cval[((size_t)node * A + act) * K + k] = child_new[k];
+          }
+        l.cvis[node * A + act] = newvis;
+        f.nv = f.nv + 1;
+        l.nv[node] = f.nv;
+      }
+      // refresh the cached selection of this node
+      NodeRow<AMAX> r;
+      az_node_row<AMAX, KMAX>(f, A, K, r);
+      bool ambiguous;
+      const int best = az_select_cached<AMAX, NOISY>(c, rc, A, p == 0, r, ambiguous);
+      int child = AZ_UNVISITED;
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a == best) child = f.cidx[a];
+      s.selx[node + 1] = az_pack_sel(best, child, ambiguous);
+    }
+  }
+  az_wave_sync();
+}
+
+#endif  // AZ_WAVE_H_

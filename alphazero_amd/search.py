@@ -112,7 +112,10 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
     Extra keyword arguments (no counterpart in the reference): `tiebreak_noise`
     injects the uniform(0,1) draws of the 1e-7 tie-break noise as a tensor
     [B, num_simulations, depth, A] (or "zero"); `stats`, a dict, receives
-    `sum_depth`, a device int64 with the summed depth of all expanded nodes.
+    `sum_depth`, a device int64 with the summed depth of all expanded nodes; on input
+    `stats['kernel_form'] = 'literal'` selects the one-thread-per-lane kernels (used to
+    cross-check the two kernel forms) and `stats['record_events']` brackets the search
+    launch with HIP events.
     `loop_fn` is accepted for signature compatibility and ignored.
     """
     del loop_fn
@@ -140,6 +143,8 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
                    interior_action_selection_fn=interior_action_selection_fn,
                    max_depth=max_depth, rng_key=rng_key,
                    tiebreak_noise=noise if noise is not None else tiebreak_noise)
+    if stats is not None and stats.get("kernel_form") == "literal":
+        d.kernel_form = 1  # cross-checks: the one-thread-per-lane kernels
     inv = None if invalid_actions is None else _f32(invalid_actions, "invalid_actions")
     if inv is not None and inv.shape != (B, A):
         raise ValueError("invalid_actions must have shape [B, num_actions]")

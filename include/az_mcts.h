@@ -49,6 +49,7 @@ typedef struct az_search_desc {
   int32_t noise_mode;          /* AZ_NOISE_*: source of the 1e-7 tie-break noise    */
   int32_t noise_depth;         /* Dn of an injected noise tensor [B,S,Dn,A]         */
   uint32_t key[2];             /* rng_key handed to search()                        */
+  int32_t kernel_form;         /* 0: automatic; 1: the one-thread-per-lane kernels  */
 } az_search_desc;
 
 /* The search tree, in exactly the reference's array layout

@@ -32,9 +32,10 @@ def make_model(model):
                            gamma=model.get("gamma", 0.99))
 
 
-def run_policy_hip(case, path="persistent"):
+def run_policy_hip(case, path="persistent", literal=False):
     """path: 'persistent' (one launch: injected or fused kernel) or 'callback'
-    (per-simulation kernels around a Python recurrent_fn)."""
+    (per-simulation kernels around a Python recurrent_fn).  literal: the one-thread-per-lane
+    form of the persistent kernels instead of the cooperative one."""
     v = case["variant"]
     B, S, A, K = case["B"], case["S"], case["A"], case["K"]
     model = case.get("model")
@@ -62,7 +63,7 @@ def run_policy_hip(case, path="persistent"):
     root = mctx.RootFnOutput(prior_logits=dev(case["prior_logits"]), value=dev(case["value"]),
                              embedding=embedding)
     inv = None if case.get("invalid") is None else dev(case["invalid"])
-    stats = {}
+    stats = {"kernel_form": "literal"} if literal else {}
     common = dict(params=(), rng_key=0, root=root, recurrent_fn=recurrent_fn, num_simulations=S,
                   invalid_actions=inv, max_depth=case.get("max_depth"),
                   qtransform=qtransform_of(case), stats=stats)

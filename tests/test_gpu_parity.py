@@ -236,21 +236,19 @@ def test_fused_equals_callback_path(hip):
     dict(variant="sampled", B=24, S=48, A=4, K=1, with_invalid=True),
     dict(variant="muzero", B=16, S=40, A=8, K=1, max_depth=6),
 ], ids=_ids)
-def test_literal_and_cooperative_tree_kernels_agree(hip, kw, monkeypatch):
+def test_literal_and_cooperative_tree_kernels_agree(hip, kw):
     """The literal one-thread-per-lane kernel and the cooperative 32-threads-per-lane kernel
     (cached selections in LDS) build bit-identical trees, and both equal the CPU checker."""
     case = _case(kw, seed=51)
     coop = hip.run_policy_hip(case, "persistent")
-    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
-    literal = hip.run_policy_hip(case, "persistent")
-    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    literal = hip.run_policy_hip(case, "persistent", literal=True)
     hip.assert_same(coop, literal)
     hip.assert_same(coop, runners.run_policy_c(case))
     assert coop["sum_depth"] > case["B"] * case["S"] or case.get("max_depth") == 1
 
 
 @pytest.mark.parametrize("variant", ["muzero", "sampled"])
-def test_cooperative_puct_when_only_the_noise_decides(hip, variant, monkeypatch):
+def test_cooperative_puct_when_only_the_noise_decides(hip, variant):
     """All priors and evaluations equal: every selection is a tie that the 1e-7 noise of
     that very visit breaks, so the cached picks are all ambiguous and re-evaluated exactly."""
     case = runners.synthetic_case(variant, B=24, S=32, A=4, K=1, seed=57)
@@ -261,9 +259,7 @@ def test_cooperative_puct_when_only_the_noise_decides(hip, variant, monkeypatch)
     ref = runners.run_policy_c(case)
     coop = hip.run_policy_hip(case, "persistent")
     hip.assert_same(coop, ref)
-    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
-    literal = hip.run_policy_hip(case, "persistent")
-    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    literal = hip.run_policy_hip(case, "persistent", literal=True)
     hip.assert_same(coop, literal)
 
 
@@ -285,13 +281,11 @@ def test_cooperative_kernel_with_zero_noise_puct(hip, oracle):
     assert np.array_equal(out.action.cpu().numpy(), ref["action"])
 
 
-def test_literal_and_cooperative_fused_kernels_agree(hip, monkeypatch):
+def test_literal_and_cooperative_fused_kernels_agree(hip):
     case = runners.synthetic_case("gumbel", B=40, S=48, K=1, seed=55, env_id="CartPole-v1",
                                   policy_hidden=(32, 32), value_hidden=(64, 64))
     coop = hip.run_policy_hip(case, "persistent")
-    monkeypatch.setenv("AZ_FORCE_LITERAL", "1")
-    literal = hip.run_policy_hip(case, "persistent")
-    monkeypatch.delenv("AZ_FORCE_LITERAL")
+    literal = hip.run_policy_hip(case, "persistent", literal=True)
     hip.assert_same(coop, literal)
     assert np.array_equal(coop["emb_state"], literal["emb_state"])
     ref = runners.run_policy_c(case)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizes computed by hand from include/az_mcts.h
-    assert C.sizeof(nat.SearchDesc) == 21 * 4
+    assert C.sizeof(nat.SearchDesc) == 22 * 4
     assert C.sizeof(nat.TreePtrs) == 13 * 8
     assert C.sizeof(nat.SearchInputs) == 4 * 8
     assert C.sizeof(nat.Injected) == 4 * 8
