@@ -317,13 +317,15 @@ AZ_DEV int az_opaque(int v) {
 // simulation: every wave walks its two lanes' trees and steps their environments, one
 // workgroup barrier hands the 16 observations to the networks, and after the networks' last
 // phase every wave updates its own two lanes -- nothing else in the loop crosses a wave.
-template <int AMAX, int KMAX, bool NOISY>
+// EXACT: A == AMAX and K == KMAX (compile-time shapes); RULE: see az_rule_ctx.
+template <int AMAX, int KMAX, bool EXACT, int RULE, bool NOISY>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
-    SearchCtx c, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
+    SearchCtx c_in, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
   static_assert(AZ_MLP_WAVES * 64 == AZ_TREE_THREADS, "one thread layout for both phases");
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SearchCtx c = az_rule_ctx<RULE>(c_in);
   const az_search_desc& d = c.d;
-  const int A = d.A, K = d.K, S = d.S;
+  const int A = EXACT ? AMAX : d.A, K = EXACT ? KMAX : d.K, S = d.S;
   MlpLds s(lds, md.pol_kp, md.val_kp);
   float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
                                              need_keys ? sim_keys : nullptr);
       else
-        wp = az_wave_chase_lean(ws, h, j, d.max_depth, active);
+        wp = az_wave_chase_lean(ws, h, j, sim, d.max_depth, active);
       AZ_SIM_STAMP(1);
       if (leader) {
         depth_sum += wp.dep;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       // The path is known now, and the rows the update will need depend on the path only: when a
       // row fits in a few registers its loads are issued before the networks run, so that
       // their latency hides behind the MLPs.
-      if (kPrefetch) az_wave_load<AMAX, KMAX>(l, ws, active, j, wp.dep, sim, P0);
+      if (kPrefetch) az_wave_load<AMAX, KMAX>(l, active, j, wp.dep, sim, wp.e_prev, wp.e_mine, P0);
       // The first unit's weights are requested before the barrier, so that they arrive while
       // the slower waves still walk their trees.  The weight registers are not kept across
       // the update below, which needs them.
@@ -441,19 +443,23 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
     const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
     const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
     if (emb_in_lds) lds2 += emb_bytes;
-    return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
-      if constexpr (AMAX <= 8 && KMAX <= 8) {
-        const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-        auto kern = noisy ? k_search_fused_wave<AMAX, KMAX, true> : k_search_fused_wave<AMAX, KMAX, false>;
-        if (int rc = az_set_lds((const void*)kern, lds2)) return rc;
-        kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
-               (hipStream_t)stream>>>(c, *t, md, emb_in_lds,
-                                      reinterpret_cast<unsigned long long*>(sum_depth));
-        AZ_LAUNCH_CHECK();
-        return AZ_OK;
-      } else {
-        return az_fail(AZ_ERR_UNSUPPORTED, "cooperative search dispatched beyond its bounds");
-      }
+    const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
+    const int rule = az_rule_of(d);
+    return az_dispatch_coop(d->A, d->K, [&]<int AMAX, int KMAX, bool EXACT>() -> int {
+      using Kern = void (*)(SearchCtx, az_tree, ModelDev, int, unsigned long long*);
+      Kern kern;
+      if (noisy)
+        kern = EXACT && rule == 2 ? k_search_fused_wave<AMAX, KMAX, EXACT, EXACT ? 2 : 0, true>
+                                  : k_search_fused_wave<AMAX, KMAX, EXACT, 0, true>;
+      else
+        kern = EXACT && rule == 1 ? k_search_fused_wave<AMAX, KMAX, EXACT, EXACT ? 1 : 0, false>
+                                  : k_search_fused_wave<AMAX, KMAX, EXACT, 0, false>;
+      if (int rc = az_set_lds((const void*)kern, lds2)) return rc;
+      kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
+             (hipStream_t)stream>>>(c, *t, md, emb_in_lds,
+                                    reinterpret_cast<unsigned long long*>(sum_depth));
+      AZ_LAUNCH_CHECK();
+      return AZ_OK;
     });
   }
   return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {

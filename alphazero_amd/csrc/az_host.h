@@ -49,6 +49,28 @@ static int az_dispatch_ak(int A, int K, F&& f) {
 #endif
 }
 
+// Instantiation of the cooperative kernels for a run-time (A, K): the shapes of the built-in
+// environments and value heads run with A and K as compile-time constants (EXACT: every
+// per-action / per-atom loop is straight-line code), everything else up to 8 x 8 with run-time
+// bounds.  Calls f.template operator()<AMAX, KMAX, EXACT>().
+template <typename F>
+static int az_dispatch_coop(int A, int K, F&& f) {
+#ifdef AZ_NARROW_BUILD
+  if (A == 2 && K == 1) return f.template operator()<2, 1, true>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A == 2 and K == 1 only");
+#else
+  if (K == 1) {
+    if (A == 2) return f.template operator()<2, 1, true>();
+    if (A == 3) return f.template operator()<3, 1, true>();
+    if (A == 4) return f.template operator()<4, 1, true>();
+  } else if (K == 8) {
+    if (A == 2) return f.template operator()<2, 8, true>();
+    if (A == 3) return f.template operator()<3, 8, true>();
+  }
+  return f.template operator()<8, 8, false>();
+#endif
+}
+
 // wave-level sum of a per-thread counter, one atomic per wave
 AZ_DEV void az_add_depth(unsigned long long* dst, long long v) {
   if (!dst) return;

@@ -9,6 +9,16 @@
 #include <string>
 #include <vector>
 
+#ifdef AZ_STAMP
+// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation.
+__device__ long long az_tree_stamps[64][8];
+#define AZ_WAVE_STAMP(k)                                                        \
+  do {                                                                          \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sim < 64)                        \
+      az_tree_stamps[sim][k] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+#endif
+
 #include "az_host.h"
 #include "az_wave.h"
 
@@ -97,12 +107,7 @@ AZ_UNROLL_K
 }
 
 #ifdef AZ_STAMP
-// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation.
-__device__ long long az_tree_stamps[64][8];
-#define AZ_TREE_STAMP(k)                                                                              \
-  do {                                                                                                \
-    if (blockIdx.x == 0 && tid == 0 && sim < 64) az_tree_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
+#define AZ_TREE_STAMP(k) AZ_WAVE_STAMP(k)
 extern "C" int az_debug_read_tree_stamps(long long* host_out) {
   AZ_HIP(hipDeviceSynchronize());
   AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_tree_stamps), sizeof(long long) * 64 * 8));
@@ -119,13 +124,15 @@ extern "C" int az_debug_read_tree_stamps(long long* host_out) {
 // the simulation loop.
 // TREE_LDS: the statistics arrays are staged in LDS for the whole search (a template parameter
 // so that the compiler sees LDS addresses and emits LDS instructions, not generic ones).
-template <int AMAX, int KMAX, bool NOISY, bool TREE_LDS>
+// EXACT: A == AMAX and K == KMAX (compile-time shapes); RULE: see az_rule_ctx.
+template <int AMAX, int KMAX, bool EXACT, int RULE, bool NOISY, bool TREE_LDS>
 __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_injected(
-    SearchCtx c, az_tree t, az_injected inj, unsigned long long* sum_depth) {
+    SearchCtx c_in, az_tree t, az_injected inj, unsigned long long* sum_depth) {
   constexpr int tree_in_lds = TREE_LDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SearchCtx c = az_rule_ctx<RULE>(c_in);
   const az_search_desc& d = c.d;
-  const int A = d.A, K = d.K, S = d.S;
+  const int A = EXACT ? AMAX : d.A, K = EXACT ? KMAX : d.K, S = d.S;
   const int tid = threadIdx.x, ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
   const int b0 = blockIdx.x * AZ_WG_LANES, b = b0 + ln;
   const bool active = b < d.B;
@@ -163,9 +170,9 @@ AZ_UNROLL_K
       wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
                                            need_keys ? sim_keys : nullptr);
     else
-      wp = az_wave_chase_lean(s, h, j, d.max_depth, active);
+      wp = az_wave_chase_lean(s, h, j, sim, d.max_depth, active);
     if (j == 0) depth_sum += wp.dep;
-    AZ_TREE_STAMP(1);
+    AZ_TREE_STAMP(2);
     // the recurrent_fn outputs of the NEXT simulation of this lane are requested here, a whole
     // simulation before the update that consumes them, so that their latency is never waited for
     {
@@ -182,7 +189,7 @@ AZ_UNROLL_K
     }
     az_wave_update<AMAX, KMAX, NOISY>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
                                       discount);
-    AZ_TREE_STAMP(2);
+    AZ_TREE_STAMP(7);
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a) ev_logits[a] = nx_logits[a];
 AZ_UNROLL_K
@@ -224,24 +231,34 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
     const size_t tree_bytes = TreeLds::words(d->S + 1, d->A, d->K) * 4;
     const int tree_in_lds = lds + tree_bytes <= 160 * 1024;
     if (tree_in_lds) lds += tree_bytes;
-    return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
-      if constexpr (AMAX <= 8 && KMAX <= 8) {
-        const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-        auto kern = noisy ? (tree_in_lds ? k_search_wave_injected<AMAX, KMAX, true, true>
-                                         : k_search_wave_injected<AMAX, KMAX, true, false>)
-                          : (tree_in_lds ? k_search_wave_injected<AMAX, KMAX, false, true>
-                                         : k_search_wave_injected<AMAX, KMAX, false, false>);
-        if (lds > 48 * 1024)
-          AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-        kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
-               (hipStream_t)stream>>>(c, *t, *inj,
-                                      reinterpret_cast<unsigned long long*>(sum_depth));
-        AZ_LAUNCH_CHECK();
-        return AZ_OK;
+    const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
+    const int rule = az_rule_of(d);
+    return az_dispatch_coop(d->A, d->K, [&]<int AMAX, int KMAX, bool EXACT>() -> int {
+      using Kern = void (*)(SearchCtx, az_tree, az_injected, unsigned long long*);
+      Kern kern;
+      // the specialised rules exist for the compile-time shapes only
+      if (noisy) {
+        if (EXACT && rule == 2)
+          kern = tree_in_lds ? k_search_wave_injected<AMAX, KMAX, EXACT, EXACT ? 2 : 0, true, true>
+                             : k_search_wave_injected<AMAX, KMAX, EXACT, EXACT ? 2 : 0, true, false>;
+        else
+          kern = tree_in_lds ? k_search_wave_injected<AMAX, KMAX, EXACT, 0, true, true>
+                             : k_search_wave_injected<AMAX, KMAX, EXACT, 0, true, false>;
       } else {
-        return az_fail(AZ_ERR_UNSUPPORTED, "cooperative search dispatched beyond its bounds");
+        if (EXACT && rule == 1)
+          kern = tree_in_lds ? k_search_wave_injected<AMAX, KMAX, EXACT, EXACT ? 1 : 0, false, true>
+                             : k_search_wave_injected<AMAX, KMAX, EXACT, EXACT ? 1 : 0, false, false>;
+        else
+          kern = tree_in_lds ? k_search_wave_injected<AMAX, KMAX, EXACT, 0, false, true>
+                             : k_search_wave_injected<AMAX, KMAX, EXACT, 0, false, false>;
       }
+      if (lds > 48 * 1024)
+        AZ_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+      kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
+             (hipStream_t)stream>>>(c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
+      AZ_LAUNCH_CHECK();
+      return AZ_OK;
     });
   }
   return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {

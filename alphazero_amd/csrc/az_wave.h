@@ -39,6 +39,13 @@
 #define AZ_TREE_THREADS (AZ_POS * AZ_WG_LANES)
 #define AZ_SEL_AMBIG (1 << 30)
 
+// Hook of the diagnostic (cycle-stamp) builds; expands to nothing otherwise.
+#ifndef AZ_WAVE_STAMP
+#define AZ_WAVE_STAMP(k) \
+  do {                   \
+  } while (0)
+#endif
+
 // Compiler-level ordering point between LDS / memory accesses of different threads of ONE wave
 // (the hardware already executes a wave's memory instructions in program order).
 AZ_DEV void az_wave_sync() {
@@ -350,52 +357,62 @@ AZ_DEV void az_wave_sim_keys(const az_search_desc& d, uint32_t* sim_keys, int ti
   __syncthreads();
 }
 
-// What the walk leaves behind for the update, the same in every thread of a lane.
+// What the walk leaves behind for the update.
 struct WavePath {
-  int dep;      // levels walked = depth of the evaluated node (0: inactive lane)
-  int dep_max;  // the larger `dep` of the wave's two lanes (wave-uniform)
+  int dep;         // levels walked = depth of the evaluated node (0: inactive lane)
+  int dep_max;     // the larger `dep` of the wave's two lanes (wave-uniform)
+  int32_t e_prev;  // the selection word the walk read at level j - 1 (j = the thread's position in pass 0)
+  int32_t e_mine;  // ... and at level j
 };
 
 // Depth of the recorded path of both lanes of the wave after a walk of `t_exit` levels
 // (entries [0, t_exit) of `path` are this simulation's; the walk wrote 0 past a lane's end).
-AZ_DEV WavePath az_wave_path_depth(const WaveLds& s, int h, int j, int t_exit, int max_depth,
-                                   bool active) {
-  int d0 = 0, d1 = 0;
-  for (int base = 0; base < t_exit; base += AZ_POS) {
-    // position p lies on the path iff the walk reached it: p == 0, or level p - 1 led to a
-    // visited child and the depth cap (search.py:183) allowed another level
+AZ_DEV void az_wave_path_depth(const WaveLds& s, int h, int j, int t_exit, int max_depth,
+                               bool active, WavePath& w) {
+  // position p lies on the path iff the walk reached it: p == 0, or level p - 1 led to a
+  // visited child and the depth cap (search.py:183) allowed another level
+  bool on = active && j < t_exit && (j == 0 || ((w.e_prev & 0xffff) != 0 && j < max_depth));
+  unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+  int d0 = __builtin_popcount((unsigned)m), d1 = __builtin_popcount((unsigned)(m >> 32));
+  for (int base = AZ_POS; base < t_exit; base += AZ_POS) {  // paths deeper than one pass
     const int p = base + j;
-    bool on = active && p < t_exit;
-    if (on && p > 0) on = (s.path[p - 1] & 0xffff) != 0 && p < max_depth;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+    on = active && p < t_exit && (s.path[p - 1] & 0xffff) != 0 && p < max_depth;
+    m = __builtin_amdgcn_ballot_w64(on);
     d0 += __builtin_popcount((unsigned)m);
     d1 += __builtin_popcount((unsigned)(m >> 32));
   }
-  WavePath w;
   w.dep = h ? d1 : d0;
   w.dep_max = d0 > d1 ? d0 : d1;
-  return w;
 }
 
 // Step 1 for the rules without per-visit noise: thread 0 of each lane follows the cached
-// selections from the root and records the selection word of every level.  The loop carries the
-// node code only -- a wave alone on its SIMD issues an instruction every four cycles or so, so a
-// level costs its instruction count as much as the LDS round trip -- and ends on one scalar test
-// per four levels; a lane whose walk has ended keeps reading selx[0] = 0 meanwhile.
-AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int max_depth, bool active) {
+// selections from the root and records the selection word of every level.  Only the LDS read,
+// one mask and the address are on the dependent chain; the loop ends on one scalar test per four
+// levels, a lane whose walk has ended keeps reading selx[0] = 0 meanwhile, and levels past the
+// depth cap (search.py:183) are walked too and discarded by az_wave_path_depth.
+AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int max_depth, bool active) {
+  (void)sim;  // named by the stamp hook of diagnostic builds
   int t = 0;
-  int k = active && j == 0 ? 1 : 0;
-  while (__builtin_amdgcn_ballot_w64(k != 0) != 0) {
+  if (j == 0) {
+    int k = active ? 1 : 0;
+    do {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int32_t e = s.selx[k];
-      if (j == 0) s.path[t] = e;
-      t += 1;
-      k = t < max_depth ? (e & 0xffff) : 0;
-    }
+      for (int u = 0; u < 4; ++u) {
+        const int32_t e = s.selx[k];
+        s.path[t + u] = e;
+        k = e & 0xffff;
+      }
+      t += 4;
+    } while (__builtin_amdgcn_ballot_w64(k != 0) != 0 && t < max_depth);
   }
+  t = __builtin_amdgcn_readlane(t, 0);
   az_wave_sync();
-  return az_wave_path_depth(s, h, j, t, max_depth, active);
+  AZ_WAVE_STAMP(1);
+  WavePath w;
+  w.e_prev = s.path[j > 0 ? j - 1 : 0];
+  w.e_mine = s.path[j];
+  az_wave_path_depth(s, h, j, t, max_depth, active, w);
+  return w;
 }
 
 // The same walk for the PUCT rules with per-visit noise: a cached pick that the noise could
@@ -434,6 +451,8 @@ AZ_DEV WavePath az_wave_chase_noisy(const SearchCtx& c, const Lane<AMAX, KMAX>& 
   WavePath w;
   w.dep = h ? d1 : d0;
   w.dep_max = d0 > d1 ? d0 : d1;
+  w.e_prev = s.path[j > 0 ? j - 1 : 0];  // entries past the path's end are stale and not used
+  w.e_mine = s.path[j];
   return w;
 }
 
@@ -454,7 +473,8 @@ AZ_DEV WaveLeaf az_wave_leaf(const WaveLds& s, int dep, int sim) {
 }
 
 // What path position p of a lane works on: its node, the action the path takes there, and the
-// node's row.  (Positions past the path's end, and inactive lanes, get an all-zero row.)
+// node's row.  Positions past the path's end (and inactive lanes) read the root's row, which is
+// always valid memory, and are kept from writing by the caller.
 template <int AMAX, int KMAX>
 struct WaveRow {
   FullRow<AMAX, KMAX> f;
@@ -462,21 +482,22 @@ struct WaveRow {
 };
 
 template <int AMAX, int KMAX>
-AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active, int p, int dep,
-                         int sim, WaveRow<AMAX, KMAX>& w) {
-  w.node = AZ_ROOT;
-  w.act = 0;
-  w.f = FullRow<AMAX, KMAX>{};
-  if (active && p <= dep) {
-    const int kc = p > 0 ? (s.path[p - 1] & 0xffff) : 1;
-    if (p == dep) {
-      w.node = kc == 0 ? sim + 1 : kc - 1;  // search.py:97-99
-    } else {
-      w.node = kc - 1;
-      w.act = (s.path[p] >> 16) & 0xff;
-    }
-    az_load_full_row<AMAX, KMAX>(l, w.node, w.f);
-  }
+AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, bool active, int p, int dep, int sim, int32_t e_prev,
+                         int32_t e_mine, WaveRow<AMAX, KMAX>& w) {
+  const bool mine = active && p <= dep, leaf = p == dep;
+  const int kc = p > 0 ? (e_prev & 0xffff) : 1;
+  const int on_path = kc - 1;
+  const int fresh = kc == 0 ? sim + 1 : kc - 1;  // search.py:97-99
+  w.node = mine ? (leaf ? fresh : on_path) : AZ_ROOT;
+  w.act = mine && !leaf ? (e_mine >> 16) & 0xff : 0;
+  az_load_full_row<AMAX, KMAX>(l, w.node, w.f);
+}
+
+// Value of wave lane i + 1 (0 for lane 63), in a form the compiler can fold into the consuming
+// multiply as its DPP operand.
+AZ_DEV float az_from_next_lane_keep(float x) {
+  const int v = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true));
 }
 
 // Step 3: expand (search.py:231-244, 304-342) and backward (search.py:265-286) applied to every
@@ -485,6 +506,15 @@ AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, const WaveLds& s, bool activ
 // thread p % 32 of the lane in pass p / 32.  ev_logits [A] / ev_value [K] / reward / discount
 // are the recurrent_fn's outputs for this lane (any address space; read by every thread).
 // `pre` (or null): the rows of pass 0, loaded by az_wave_load ahead of the evaluation.
+//
+// The backup's value chain  lv(p) = reward(p) + discount(p) * lv(p + 1)  runs as a fixed-point
+// iteration over the wave's lanes: every step, every thread recomputes its value from the one
+// its next lane held a step earlier (one DPP multiply-add pair).  The deepest path position
+// reads a constant (the evaluated node's value), so after u steps the u deepest positions hold
+// their final values and recomputing them changes nothing; no thread needs to know when its
+// turn is.  Threads past the path's end hand the constant through unchanged (-0.0f + 1.0f * x
+// is x for every x), and thread 31 of each lane is pinned so that nothing leaks in from the
+// neighbouring lane of the wave.
 template <int AMAX, int KMAX, bool NOISY>
 AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active,
                            int h, int j, int sim, const WavePath& wp, const float* ev_logits,
@@ -493,10 +523,12 @@ AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const 
   const int A = l.A, K = l.K;
   const int dep = wp.dep;
   const RootCache rc = s.root_cache(c);
-  float carry_x[KMAX], carry_child[KMAX];
+  const bool top = j == AZ_POS - 1;
+  float ev[KMAX], carry_x[KMAX], carry_child[KMAX];
 AZ_UNROLL_K
   for (int k = 0; k < AZ_TRIP_K; ++k) {
-    carry_x[k] = k < K && active ? ev_value[k] : 0.0f;  // backward starts from the evaluated node's value
+    ev[k] = k < K ? ev_value[k] : 0.0f;
+    carry_x[k] = ev[k];  // backward starts from the evaluated node's value
     carry_child[k] = 0.0f;
   }
   for (int it = wp.dep_max / AZ_POS; it >= 0; --it) {
@@ -504,67 +536,74 @@ AZ_UNROLL_K
     const bool mine = active && p <= dep;
     const bool leaf = p == dep;
     WaveRow<AMAX, KMAX> w;
-    if (pre != nullptr && it == 0)
+    if (pre != nullptr && it == 0) {
       w = *pre;
-    else
-      az_wave_load<AMAX, KMAX>(l, s, active, p, dep, sim, w);
+    } else if (it == 0) {
+      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, wp.e_prev, wp.e_mine, w);
+    } else {
+      const int pp = p <= dep ? p : dep;  // keeps the reads of unused positions inside the path
+      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, s.path[pp - 1], s.path[pp], w);
+    }
     FullRow<AMAX, KMAX>& f = w.f;
     const int node = w.node, act = w.act;
+    AZ_WAVE_STAMP(3);
     // the edge from this position's node to the next node of the path
-    float r_p = 0.0f, d_p = 0.0f;
-AZ_UNROLL_A
-    for (int a = 0; a < AZ_TRIP_A; ++a)
-      if (a == act) {
-        r_p = f.rew[a];
-        d_p = f.disc[a];
-      }
-    if (p == dep - 1) {
-      r_p = reward;
-      d_p = discount;
-    }
-    // backward's value chain, leaf -> root: at step u the thread whose turn it is holds, in x,
-    // the value its child position computed one step earlier (the deepest one starts from the
-    // block's carry-in), computes its own, and every thread hands its result one lane down.
     const int jstart = dep - 1 - it * AZ_POS < AZ_POS - 1 ? dep - 1 - it * AZ_POS : AZ_POS - 1;
     const int js_max = wp.dep_max - 1 - it * AZ_POS < AZ_POS - 1 ? wp.dep_max - 1 - it * AZ_POS : AZ_POS - 1;
-    const int myturn = jstart - j;
-    float x[KMAX], lv[KMAX];
+    float r_p = -0.0f, d_p = 1.0f;
+    if (active && j <= jstart) {
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a == act) {
+          r_p = f.rew[a];
+          d_p = f.disc[a];
+        }
+      if (p == dep - 1) {
+        r_p = reward;
+        d_p = discount;
+      }
+    }
+    float y[KMAX], pin[KMAX];
 AZ_UNROLL_K
     for (int k = 0; k < AZ_TRIP_K; ++k) {
-      x[k] = carry_x[k];
-      lv[k] = 0.0f;
+      y[k] = carry_x[k];
+      pin[k] = jstart == AZ_POS - 1 ? r_p + d_p * carry_x[k] : carry_x[k];
     }
-    for (int u = 0; u <= js_max; ++u) {
-      const bool turn = u == myturn;
+    for (int u = 0; u <= js_max; u += 4) {  // steps past the last needed one change nothing
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
 AZ_UNROLL_K
-      for (int k = 0; k < AZ_TRIP_K; ++k)
-        if (k < K) {
-          const float y = r_p + d_p * x[k];
-          lv[k] = turn ? y : lv[k];
-          x[k] = az_from_next_lane(y);
-        }
+        for (int k = 0; k < AZ_TRIP_K; ++k)
+          if (k < K) {
+            const float v = r_p + d_p * az_from_next_lane_keep(y[k]);
+            y[k] = top ? pin[k] : v;
+          }
+      }
     }
+    AZ_WAVE_STAMP(4);
     // the node's new value; its child's new value arrives from the next lane
     const float cnt = (float)f.nv;
     float nval_new[KMAX], child_new[KMAX];
 AZ_UNROLL_K
     for (int k = 0; k < AZ_TRIP_K; ++k) {
       nval_new[k] = 0.0f;
-      if (k < K) nval_new[k] = leaf ? (active ? ev_value[k] : 0.0f) : (f.nval[k] * cnt + lv[k]) / (cnt + 1.0f);
+      if (k < K) nval_new[k] = leaf ? ev[k] : (f.nval[k] * cnt + y[k]) / (cnt + 1.0f);
       child_new[k] = az_from_next_lane(nval_new[k]);
     }
     if (wp.dep_max >= AZ_POS) {  // several passes: hand the block's lowest position to the next pass
 AZ_UNROLL_K
       for (int k = 0; k < AZ_TRIP_K; ++k) {
-        if (j == AZ_POS - 1) child_new[k] = carry_child[k];
-        const float lv0 = __shfl(lv[k], 0, AZ_POS), nv0 = __shfl(nval_new[k], 0, AZ_POS);
-        if (jstart >= 0) carry_x[k] = lv0;
+        if (top) child_new[k] = carry_child[k];
+        const float y0 = __shfl(y[k], 0, AZ_POS), nv0 = __shfl(nval_new[k], 0, AZ_POS);
+        if (jstart >= 0) carry_x[k] = y0;
         carry_child[k] = nv0;
       }
     }
+    AZ_WAVE_STAMP(5);
     if (mine) {
+      // expand at the evaluated node (update_tree_node, search.py:304-342), backward
+      // (search.py:265-286) at the nodes of the path
       if (leaf) {
-        // the evaluated node (update_tree_node, search.py:304-342)
         const WaveLeaf wl = az_wave_leaf(s, dep, sim);
 AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -575,13 +614,9 @@ AZ_UNROLL_A
 AZ_UNROLL_K
         for (int k = 0; k < AZ_TRIP_K; ++k)
           if (k < K) {
-            f.raw[k] = ev_value[k];
-            f.nval[k] = ev_value[k];
-            l.raw[(size_t)node * K + k] = f.raw[k];
-            l.nval[(size_t)node * K + k] = f.nval[k];
+            f.raw[k] = ev[k];
+            l.raw[(size_t)node * K + k] = ev[k];
           }
-        f.nv = f.nv + 1;
-        l.nv[node] = f.nv;
         l.par[node] = wl.parent;
         l.afp[node] = wl.action;
       } else {
@@ -599,7 +634,6 @@ AZ_UNROLL_A
           l.crew[node * A + act] = reward;
           l.cdisc[node * A + act] = discount;
         }
-        // backward (search.py:265-286) at this node
         int32_t newvis = 0;
 AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -612,15 +646,18 @@ AZ_UNROLL_K
           }
 AZ_UNROLL_K
         for (int k = 0; k < AZ_TRIP_K; ++k)
-          if (k < K) {
-            f.nval[k] = nval_new[k];
-            l.nval[(size_t)node * K + k] = nval_new[k];
-            l.cval[((size_t)node * A + act) * K + k] = child_new[k];
-          }
+          if (k < K) l.cval[((size_t)node * A + act) * K + k] = child_new[k];
         l.cvis[node * A + act] = newvis;
-        f.nv = f.nv + 1;
-        l.nv[node] = f.nv;
       }
+AZ_UNROLL_K
+      for (int k = 0; k < AZ_TRIP_K; ++k)
+        if (k < K) {
+          f.nval[k] = nval_new[k];
+          l.nval[(size_t)node * K + k] = nval_new[k];
+        }
+      f.nv = f.nv + 1;
+      l.nv[node] = f.nv;
+      AZ_WAVE_STAMP(6);
       // refresh the cached selection of this node
       NodeRow<AMAX> r;
       az_node_row<AMAX, KMAX>(f, A, K, r);
@@ -634,6 +671,30 @@ AZ_UNROLL_A
     }
   }
   az_wave_sync();
+}
+
+// The search descriptor with the fields a compile-time rule fixes replaced by constants, so that
+// the selection code folds to that rule alone.  RULE 0: everything at run time; 1: the Gumbel
+// rules with qtransform_completed_by_mix_value at its defaults (policies.py:237-250);
+// 2: a PUCT rule (muzero or sampled) with qtransform_by_parent_and_siblings (policies.py:30-45).
+template <int RULE>
+AZ_DEV SearchCtx az_rule_ctx(const SearchCtx& c) {
+  SearchCtx cc = c;
+  if (RULE == 1) {
+    cc.d.variant = AZ_VARIANT_GUMBEL;
+    cc.d.qtransform = AZ_QT_COMPLETED_MIX;
+    cc.d.use_mixed_value = 1;
+    cc.d.rescale_values = 1;
+  } else if (RULE == 2) {
+    cc.d.qtransform = AZ_QT_PARENT_SIBLINGS;
+  }
+  return cc;
+}
+// The rule a descriptor can run under (host side).
+inline int az_rule_of(const az_search_desc* d) {
+  if (d->variant == AZ_VARIANT_GUMBEL)
+    return d->qtransform == AZ_QT_COMPLETED_MIX && d->use_mixed_value && d->rescale_values ? 1 : 0;
+  return d->qtransform == AZ_QT_PARENT_SIBLINGS ? 2 : 0;
 }
 
 #endif  // AZ_WAVE_H_

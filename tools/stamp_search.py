@@ -22,16 +22,13 @@ lib = nat.lib()
 buf = np.zeros((64, 16), np.int64)
 lib.az_debug_read_sim_stamps.argtypes = [C.c_void_p]
 lib.az_debug_read_sim_stamps(buf.ctypes.data_as(C.c_void_p))
-names = ["chase", "env+obs", "sync", "MLP", "hdr", "load0", "sync0", "apply0", "load1", "sync1", "apply1"]
-print("sim   total | " + " ".join(f"{n:>7}" for n in names))
-for sim in range(S):
+names = ["walk", "env+rows", "barrier", "MLP", "update"]
+print("sim   total | " + " ".join(f"{n:>8}" for n in names))
+tot_sum = np.zeros(6)
+for sim in range(min(S, 64)):
     row = buf[sim]
-    nxt = buf[sim + 1][0] if sim + 1 < S else 0
-    seq = [row[0], row[1], row[2], row[3], row[4], row[5], row[6], row[7]]
-    d = [int(seq[i + 1] - seq[i]) for i in range(7)]
-    extra = []
-    if row[8] > row[7]:
-        extra = [int(row[8] - row[7]), int(row[9] - row[8]), int(row[10] - row[9])]
-    # names: chase=1-0, env=2-1, sync=3-2, MLP=4-3, load0=5-4, sync0=6-5, apply0=7-6
-    tot = int(nxt - row[0]) if nxt else -1
-    print(f"{sim:3d} {tot:7d} | " + " ".join(f"{x:7d}" for x in d + extra))
+    nxt = buf[sim + 1][0] if sim + 1 < min(S, 64) else row[5]
+    d = [int(row[i + 1] - row[i]) for i in range(4)] + [int(nxt - row[4])]
+    tot_sum += np.array([int(nxt - row[0])] + d)
+    print(f"{sim:3d} {int(nxt - row[0]):7d} | " + " ".join(f"{x:8d}" for x in d))
+print("mean", " ".join(f"{x:8.0f}" for x in tot_sum / min(S, 64)))

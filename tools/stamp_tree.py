@@ -20,10 +20,10 @@ lib = nat.lib()
 buf = np.zeros((64, 8), np.int64)
 lib.az_debug_read_tree_stamps.argtypes = [C.c_void_p]
 lib.az_debug_read_tree_stamps(buf.ctypes.data_as(C.c_void_p))
-names = ["chase", "sync", "fill+load", "sync", "apply", "sync", "top"]
+names = ["walk", "depth", "prefetch", "rows", "chain", "values", "writes", "select"]
 print("sim   total | " + " ".join(f"{n:>9}" for n in names))
 for sim in range(min(S, 64)):
     r = buf[sim]
-    nxt = buf[sim + 1][0] if sim + 1 < min(S, 64) else r[6]
-    d = [int(r[i + 1] - r[i]) for i in range(6)] + [int(nxt - r[6])]
+    nxt = buf[sim + 1][0] if sim + 1 < min(S, 64) else r[7]
+    d = [int(r[i + 1] - r[i]) for i in range(7)] + [int(nxt - r[7])]
     print(f"{sim:3d} {int(nxt - r[0]):7d} | " + " ".join(f"{x:9d}" for x in d))
