@@ -342,7 +342,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
   az_stage_inputs(md, s, tid, blockDim.x);
   if (j == 0) {
-    ws.selx[0] = 0;
+    ws.selx[0] = az_i32x4{0, 0, 0, 0};
     if (active) {
       Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
       az_wave_init<AMAX, KMAX, NOISY>(c, l, ws, b);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
       const float reward = az_u2f((uint32_t)ws.hdr[4]), discount = az_u2f((uint32_t)ws.hdr[5]);
-      az_wave_update<AMAX, KMAX, NOISY>(c, l, ws, active, h, j, sim, wp, s.logits + ln * AZ_MAX_ACTIONS,
+      az_wave_update<AMAX, KMAX, NOISY, RULE == 1>(c, l, ws, active, h, j, sim, wp, s.logits + ln * AZ_MAX_ACTIONS,
                                         s.value + ln * AZ_MAX_ATOMS, reward, discount,
                                         kPrefetch ? &P0 : nullptr);
       AZ_SIM_STAMP(5);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_injected(
   Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
-  if (j == 0) s.selx[0] = 0;
+  if (j == 0) s.selx[0] = az_i32x4{0, 0, 0, 0};
   __syncthreads();
   if (j == 0 && active) az_wave_init<AMAX, KMAX, NOISY>(c, l, s, b);
   __syncthreads();
@@ -187,7 +187,7 @@ AZ_UNROLL_K
       nx_reward = inj.reward[e];
       nx_discount = inj.discount[e];
     }
-    az_wave_update<AMAX, KMAX, NOISY>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
+    az_wave_update<AMAX, KMAX, NOISY, RULE == 1>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
                                       discount);
     AZ_TREE_STAMP(7);
 AZ_UNROLL_A

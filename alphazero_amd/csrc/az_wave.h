@@ -60,24 +60,30 @@ AZ_DEV float az_from_next_lane(float x) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
 }
 
-// Per-lane words of LDS.  selx[k] is the cached selection of node k - 1:
-// (action << 16) | (child + 1) [| AZ_SEL_AMBIG]; selx[0] = 0 is what a finished walk keeps reading.
-// path[t] is the selection word the walk read at level t.
+// Per-lane words of LDS.  selx[k] is the cached selection of node k - 1, four words:
+//   .x = (action << 16) | (child + 1) [| AZ_SEL_AMBIG]   the node's own selection
+//   .y, .z, .w = the .x words of the next three nodes that selection chain leads to (0 from the
+//                first unvisited child on)
+// so that the walk covers four levels per LDS round trip.  selx[0] = 0 is what a finished walk
+// keeps reading.  path[t] is the selection word (.x form) of the node at level t.
+typedef __attribute__((ext_vector_type(4))) int az_i32x4;
 struct WaveLds {
-  int32_t* selx;      // [S + 2]
-  int32_t* path;      // [S + 4]
+  az_i32x4* selx;     // [S + 2]
+  int32_t* path;      // [S + 8]
   float* root_g;      // [8] the root's Gumbel noise
   float* root_inv;    // [8] the root's invalid-action mask
+  float* root_glg;    // [8] gumbel + (logits - max logits) of the root (seq_halving.py:30-32)
   int32_t* hdr;       // [8] 4, 5: reward / discount bits of the evaluation; 7: table row
   int32_t* root_tab;  // [S] the row of the considered-visits table this lane uses
-  __host__ __device__ static inline int lane_words(int S) { return 3 * S + 32; }
+  __host__ __device__ static inline int lane_words(int S) { return (6 * S + 48 + 3) & ~3; }  // 16-byte rows
   AZ_DEV WaveLds(float* base, int lane, int S) {
     float* p = base + (size_t)lane * lane_words(S);
-    selx = reinterpret_cast<int32_t*>(p);
-    path = selx + (S + 2);
-    root_g = p + 2 * S + 6;
+    selx = reinterpret_cast<az_i32x4*>(p);
+    path = reinterpret_cast<int32_t*>(p) + 4 * (S + 2);
+    root_g = p + 5 * S + 16;
     root_inv = root_g + 8;
-    hdr = reinterpret_cast<int32_t*>(root_inv + 8);
+    root_glg = root_inv + 8;
+    hdr = reinterpret_cast<int32_t*>(root_glg + 8);
     root_tab = hdr + 8;
   }
   // Copies of the root-only selection inputs (filled by az_wave_init): the root is re-selected
@@ -311,6 +317,11 @@ AZ_DEV void az_wave_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const Wa
     s.root_g[a] = c.in.root_gumbel ? c.in.root_gumbel[(size_t)b * A + a] : 0.0f;
     s.root_inv[a] = c.in.invalid_actions ? c.in.invalid_actions[(size_t)b * A + a] : 0.0f;
   }
+  {  // the part of the root's score that no simulation changes (az_score_considered)
+    float mx = l.clog[0];
+    for (int a = 1; a < A; ++a) mx = az_maxf(mx, l.clog[a]);
+    for (int a = 0; a < A; ++a) s.root_glg[a] = s.root_g[a] + (l.clog[a] - mx);
+  }
   s.hdr[7] = -1;
   if (c.d.variant == AZ_VARIANT_GUMBEL && c.in.table) {
     float nvalid = 0.0f;
@@ -329,7 +340,7 @@ AZ_DEV void az_wave_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const Wa
 AZ_UNROLL_A
   for (int i = 0; i < AZ_TRIP_A; ++i)
     if (i == a) child = f.cidx[i];
-  s.selx[AZ_ROOT + 1] = az_pack_sel(a, child, ambiguous);
+  s.selx[AZ_ROOT + 1] = az_i32x4{az_pack_sel(a, child, ambiguous), 0, 0, 0};  // no child of a fresh root is visited
 }
 
 // The simulate keys of all S simulations into `sim_keys` ([S][2] words of LDS): the rng chain
@@ -386,23 +397,25 @@ AZ_DEV void az_wave_path_depth(const WaveLds& s, int h, int j, int t_exit, int m
 }
 
 // Step 1 for the rules without per-visit noise: thread 0 of each lane follows the cached
-// selections from the root and records the selection word of every level.  Only the LDS read,
-// one mask and the address are on the dependent chain; the loop ends on one scalar test per four
-// levels, a lane whose walk has ended keeps reading selx[0] = 0 meanwhile, and levels past the
-// depth cap (search.py:183) are walked too and discarded by az_wave_path_depth.
+// selections from the root, four levels per LDS round trip, and records the selection word of
+// every level.  Only the LDS read, one mask and the address are on the dependent chain; the loop
+// ends on one scalar test per eight levels, a lane whose walk has ended keeps reading
+// selx[0] = 0 meanwhile, and levels past the depth cap (search.py:183) are walked too and
+// discarded by az_wave_path_depth.
 AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int max_depth, bool active) {
   (void)sim;  // named by the stamp hook of diagnostic builds
   int t = 0;
   if (j == 0) {
     int k = active ? 1 : 0;
+    az_i32x4* path4 = reinterpret_cast<az_i32x4*>(s.path);
     do {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int32_t e = s.selx[k];
-        s.path[t + u] = e;
-        k = e & 0xffff;
+      for (int u = 0; u < 2; ++u) {
+        const az_i32x4 e = s.selx[k];  // this level and the next three
+        path4[t / 4 + u] = e;
+        k = e.w & 0xffff;
       }
-      t += 4;
+      t += 8;
     } while (__builtin_amdgcn_ballot_w64(k != 0) != 0 && t < max_depth);
   }
   t = __builtin_amdgcn_readlane(t, 0);
@@ -429,7 +442,7 @@ AZ_DEV WavePath az_wave_chase_noisy(const SearchCtx& c, const Lane<AMAX, KMAX>& 
     uint32_t k0 = 0u, k1 = 0u;
     int key_depth = -1;  // -1: the lane's key of this simulation has not been derived yet
     for (;;) {
-      int32_t e = s.selx[node + 1];
+      int32_t e = s.selx[node + 1].x;
       if (e & AZ_SEL_AMBIG) {
         if (key_depth < 0) {
           if (sim_keys) az_key_split(sim_keys[2 * sim], sim_keys[2 * sim + 1], (uint32_t)b, &k0, &k1);
@@ -479,6 +492,7 @@ template <int AMAX, int KMAX>
 struct WaveRow {
   FullRow<AMAX, KMAX> f;
   int node, act;
+  int e_mine_code;  // code (index + 1) of the path's next node; meaningful below the parent
 };
 
 template <int AMAX, int KMAX>
@@ -490,7 +504,140 @@ AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, bool active, int p, int dep,
   const int fresh = kc == 0 ? sim + 1 : kc - 1;  // search.py:97-99
   w.node = mine ? (leaf ? fresh : on_path) : AZ_ROOT;
   w.act = mine && !leaf ? (e_mine >> 16) & 0xff : 0;
+  w.e_mine_code = e_mine & 0xffff;
   az_load_full_row<AMAX, KMAX>(l, w.node, w.f);
+}
+
+// The Gumbel rules with qtransform_completed_by_mix_value at its defaults
+// (action_selection.py:148-240, qtransforms.py:90-198), split in two so that the part that does
+// not depend on the backup -- the prior softmax, everything derived from the visit counts --
+// can be issued ahead of it and overlap with it.  The operations, their operands and their
+// order are those of az_qt_completed_mix / az_gumbel_interior_tail / az_gumbel_root_tail; only
+// their placement differs, and nothing is evaluated under a branch.
+template <int AMAX>
+struct GumbelPre {
+  float probs[AMAX];  // max(tiny, softmax(prior logits))
+  float ratio[AMAX];  // visits / (1 + sum of visits)
+  float sum_probs, fsum, fsum1, scale;
+  int32_t sum_visits;
+};
+
+// IEEE 754-2019 maximum / minimum (one instruction each on gfx950).  Like jnp.maximum / minimum
+// (az_maxf / az_minf) they return NaN when either operand is NaN; they differ from them in the
+// sign of a zero result and in the NaN's payload only, neither of which reaches the picked action.
+AZ_DEV float az_max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+AZ_DEV float az_min_nan(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+
+// jax.nn.softmax as az_softmax, with the one-instruction maximum.
+template <int AMAX>
+AZ_DEV void az_softmax_fast(const float (&x)[AMAX], int A, float (&out)[AMAX]) {
+  float m = x[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A) m = az_max_nan(m, x[a]);
+  float s = 0.0f;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      out[a] = az_expf(x[a] - m);
+      s = s + out[a];
+    }
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) out[a] = out[a] / s;
+}
+
+// An optimisation barrier: the value is computed here, unconditionally.
+AZ_DEV float az_pin(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// vis: the children's visit counts AFTER this simulation's backup (they are known from the path).
+template <int AMAX>
+AZ_DEV void az_gumbel_pre(const az_search_desc& d, int A, const float (&logits)[AMAX],
+                          const int32_t (&vis)[AMAX], GumbelPre<AMAX>& g) {
+  az_softmax_fast<AMAX>(logits, A, g.probs);
+  int32_t sum_visits = 0, maxvisit = vis[0];
+  g.sum_probs = 0.0f;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      sum_visits += vis[a];
+      if (a > 0 && vis[a] > maxvisit) maxvisit = vis[a];
+      g.probs[a] = az_max_nan(AZ_FLT_TINY, g.probs[a]);
+      g.sum_probs = g.sum_probs + (vis[a] > 0 ? g.probs[a] : 0.0f);
+    }
+  g.sum_visits = sum_visits;
+  g.fsum = (float)sum_visits;
+  g.fsum1 = (float)(sum_visits + 1);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      g.ratio[a] = az_pin((float)vis[a] / g.fsum1);
+      g.probs[a] = az_pin(g.probs[a]);  // (computed here, not sunk to its use behind the backup)
+    }
+  g.sum_probs = az_pin(g.sum_probs);
+  g.scale = az_pin((d.maxvisit_init + (float)maxvisit) * d.value_scale);
+}
+
+// q: mean over atoms of reward + discount * child value per action; raw: mean raw value.
+template <int AMAX>
+AZ_DEV int az_gumbel_post(const SearchCtx& c, int A, const GumbelPre<AMAX>& g, const float (&logits)[AMAX],
+                          const int32_t (&vis)[AMAX], const float (&q)[AMAX], float raw, bool root,
+                          const RootCache& rc, const float* glg) {
+  const az_search_desc& d = c.d;
+  float weighted_q = 0.0f;
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      const float t = az_pin((g.probs[a] * q[a]) / g.sum_probs);
+      weighted_q = weighted_q + (vis[a] > 0 ? t : 0.0f);
+    }
+  const float value = (raw + g.fsum * weighted_q) / g.fsum1;
+  float cq[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) cq[a] = vis[a] > 0 ? q[a] : value;
+  float mn = cq[0], mx = cq[0];
+AZ_UNROLL_A
+  for (int a = 1; a < AZ_TRIP_A; ++a)
+    if (a < A) {
+      mn = az_min_nan(mn, cq[a]);
+      mx = az_max_nan(mx, cq[a]);
+    }
+  const float den = az_max_nan(mx - mn, d.q_epsilon);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) cq[a] = g.scale * ((cq[a] - mn) / den);
+  // interior rule (action_selection.py:203-240)
+  float x[AMAX], p2[AMAX], to_argmax[AMAX];
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) x[a] = logits[a] + cq[a];
+  az_softmax_fast<AMAX>(x, A, p2);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) to_argmax[a] = p2[a] - g.ratio[a];
+  int best = az_argmax<AMAX>(to_argmax, A);
+  if (root) {
+    // root rule (action_selection.py:148-200, seq_halving.py:23-33): the number of considered
+    // actions is fixed per search, so the table row is the cached one, and gumbel + (logits -
+    // max logits) was added up once by az_wave_init
+    int32_t sim_index = g.sum_visits;
+    if (sim_index > d.S - 1) sim_index = d.S - 1;
+    const int32_t considered_visit = rc.table_row[sim_index];
+    float score[AMAX];
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) {
+        const float penalty = vis[a] == considered_visit ? 0.0f : -AZ_INF;
+        score[a] = az_max_nan(-1e9f, glg[a] + cq[a]) + penalty;
+        if (rc.has_invalid && rc.invalid[a] != 0.0f) score[a] = -AZ_INF;
+      }
+    best = az_argmax<AMAX>(score, A);
+  }
+  return best;
 }
 
 // Value of wave lane i + 1 (0 for lane 63), in a form the compiler can fold into the consuming
@@ -515,7 +662,7 @@ AZ_DEV float az_from_next_lane_keep(float x) {
 // turn is.  Threads past the path's end hand the constant through unchanged (-0.0f + 1.0f * x
 // is x for every x), and thread 31 of each lane is pinned so that nothing leaks in from the
 // neighbouring lane of the wave.
-template <int AMAX, int KMAX, bool NOISY>
+template <int AMAX, int KMAX, bool NOISY, bool FAST_GUMBEL = false>
 AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active,
                            int h, int j, int sim, const WavePath& wp, const float* ev_logits,
                            const float* ev_value, float reward, float discount,
@@ -525,6 +672,7 @@ AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const 
   const RootCache rc = s.root_cache(c);
   const bool top = j == AZ_POS - 1;
   float ev[KMAX], carry_x[KMAX], carry_child[KMAX];
+  int32_t carry_sel[3] = {0, 0, 0};
 AZ_UNROLL_K
   for (int k = 0; k < AZ_TRIP_K; ++k) {
     ev[k] = k < K ? ev_value[k] : 0.0f;
@@ -547,6 +695,18 @@ AZ_UNROLL_K
     FullRow<AMAX, KMAX>& f = w.f;
     const int node = w.node, act = w.act;
     AZ_WAVE_STAMP(3);
+    // What the refreshed selection needs besides the backup's result: the evaluated node takes the
+    // new prior logits, the path's nodes one more visit of the action the path took.
+    GumbelPre<AMAX> gpre;
+    if (FAST_GUMBEL) {
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < A) {
+          if (leaf) f.logits[a] = ev_logits[a];
+          if (!leaf && a == act) f.vis[a] = f.vis[a] + 1;
+        }
+      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre);
+    }
     // the edge from this position's node to the next node of the path
     const int jstart = dep - 1 - it * AZ_POS < AZ_POS - 1 ? dep - 1 - it * AZ_POS : AZ_POS - 1;
     const int js_max = wp.dep_max - 1 - it * AZ_POS < AZ_POS - 1 ? wp.dep_max - 1 - it * AZ_POS : AZ_POS - 1;
@@ -600,11 +760,12 @@ AZ_UNROLL_K
       }
     }
     AZ_WAVE_STAMP(5);
+    int32_t sel_new = 0;
+    const WaveLeaf wl = az_wave_leaf(s, dep > 0 ? dep : 1, sim);  // (an inactive lane reads level 0)
     if (mine) {
       // expand at the evaluated node (update_tree_node, search.py:304-342), backward
       // (search.py:265-286) at the nodes of the path
       if (leaf) {
-        const WaveLeaf wl = az_wave_leaf(s, dep, sim);
 AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a)
           if (a < A) {
@@ -622,7 +783,7 @@ AZ_UNROLL_K
       } else {
         if (p == dep - 1) {
           // the edge parent -> evaluated node (search.py:235-241)
-          const int newn = az_wave_leaf(s, dep, sim).node;
+          const int newn = wl.node;
 AZ_UNROLL_A
           for (int a = 0; a < AZ_TRIP_A; ++a)
             if (a == act) {
@@ -641,7 +802,7 @@ AZ_UNROLL_A
 AZ_UNROLL_K
             for (int k = 0; k < AZ_TRIP_K; ++k)
               if (k < K) f.cval[a][k] = child_new[k];
-            f.vis[a] = f.vis[a] + 1;
+            if (!FAST_GUMBEL) f.vis[a] = f.vis[a] + 1;  // (counted ahead of the backup otherwise)
             newvis = f.vis[a];
           }
 AZ_UNROLL_K
@@ -658,17 +819,59 @@ AZ_UNROLL_K
       f.nv = f.nv + 1;
       l.nv[node] = f.nv;
       AZ_WAVE_STAMP(6);
-      // refresh the cached selection of this node
+      if (!FAST_GUMBEL) {
+        // refresh the cached selection of this node
+        NodeRow<AMAX> r;
+        az_node_row<AMAX, KMAX>(f, A, K, r);
+        bool ambiguous;
+        const int best = az_select_cached<AMAX, NOISY>(c, rc, A, p == 0, r, ambiguous);
+        int child = AZ_UNVISITED;
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a == best) child = f.cidx[a];
+        sel_new = az_pack_sel(best, child, ambiguous);
+      }
+    }
+    if (FAST_GUMBEL) {
+      // refresh the cached selection: every thread runs the rule (no branch around it), the
+      // threads without a node on a row nobody uses
       NodeRow<AMAX> r;
       az_node_row<AMAX, KMAX>(f, A, K, r);
-      bool ambiguous;
-      const int best = az_select_cached<AMAX, NOISY>(c, rc, A, p == 0, r, ambiguous);
+      const int best = az_gumbel_post<AMAX>(c, A, gpre, f.logits, f.vis, r.q, r.rawmean, mine && p == 0, rc, s.root_glg);
       int child = AZ_UNVISITED;
 AZ_UNROLL_A
       for (int a = 0; a < AZ_TRIP_A; ++a)
         if (a == best) child = f.cidx[a];
-      s.selx[node + 1] = az_pack_sel(best, child, ambiguous);
+      sel_new = mine ? az_pack_sel(best, child) : 0;
     }
+    // The other words of the entry: the selections of the next three nodes down the chain.  A
+    // child on the path was refreshed just now by the next lane, whose own words two and three
+    // settle one round after its first (three rounds of one-lane shifts); any other child's entry
+    // did not change in this simulation (a node changes only together with its parent) and is
+    // read back from LDS -- the entry of code 0, for an unvisited child, reads as 0.
+    const int child_code = sel_new & 0xffff;
+    const int next_code = leaf ? 0 : (p == dep - 1 ? wl.node + 1 : w.e_mine_code);
+    az_i32x4 entry = {sel_new, 0, 0, 0};
+    if (!NOISY) {
+      const bool on_path = child_code != 0 && child_code == next_code;
+      const az_i32x4 stored = s.selx[child_code];
+      const bool several = wp.dep_max >= AZ_POS;
+      int32_t n0 = __builtin_amdgcn_update_dpp(0, entry.x, 0x130, 0xf, 0xf, false);
+      if (several && top) n0 = carry_sel[0];
+      entry.y = on_path ? n0 : stored.x;
+      int32_t n1 = __builtin_amdgcn_update_dpp(0, entry.y, 0x130, 0xf, 0xf, false);
+      if (several && top) n1 = carry_sel[1];
+      entry.z = on_path ? n1 : stored.y;
+      int32_t n2 = __builtin_amdgcn_update_dpp(0, entry.z, 0x130, 0xf, 0xf, false);
+      if (several && top) n2 = carry_sel[2];
+      entry.w = on_path ? n2 : stored.z;
+      if (several) {
+        carry_sel[0] = __shfl(entry.x, 0, AZ_POS);
+        carry_sel[1] = __shfl(entry.y, 0, AZ_POS);
+        carry_sel[2] = __shfl(entry.z, 0, AZ_POS);
+      }
+    }
+    if (mine) s.selx[node + 1] = entry;
   }
   az_wave_sync();
 }
