@@ -119,9 +119,21 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
 // running_statistics.py:183-199 on one observation row, written in the permuted
 // activation layout of the first dense layer (both networks read the same rows).
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
+  // all reads first, then the divisions side by side, then the writes: one LDS round trip and
+  // one division's latency instead of one of each per element (obs_dim <= 6, EnvOut)
   const int kp = md.val.kp[0];
-  for (int i = 0; i < md.obs_dim; ++i)
-    s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = (obs[i] - s.norm_mean[i]) / s.norm_std[i];
+  float mean[6], dev[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int ii = i < md.obs_dim ? i : 0;
+    mean[i] = s.norm_mean[ii];
+    dev[i] = s.norm_std[ii];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = (obs[i < md.obs_dim ? i : 0] - mean[i]) / dev[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (i < md.obs_dim) s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = x[i];
 }
 
 // Kernel prologue: zeroes the first layer's input rows and copies the normaliser into
@@ -384,7 +396,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         }
         EnvOut o;
         float reward, discount;
+        AZ_SIM_STAMP(6);
         az_model_env_step(md, st, wl.action, o, reward, discount);
+        AZ_SIM_STAMP(7);
         if (emb) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) emb[wl.node * 5 + i] = st.s[i];
@@ -397,11 +411,13 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         ws.hdr[4] = (int32_t)az_f2u(reward);
         ws.hdr[5] = (int32_t)az_f2u(discount);
         az_store_obs(md, s, ln, o.obs);
+        AZ_SIM_STAMP(8);
       }
       // The path is known now, and the rows the update will need depend on the path only: when a
       // row fits in a few registers its loads are issued before the networks run, so that
       // their latency hides behind the MLPs.
       if (kPrefetch) az_wave_load<AMAX, KMAX>(l, active, j, wp.dep, sim, wp.e_prev, wp.e_mine, P0);
+      AZ_SIM_STAMP(9);
       // The first unit's weights are requested before the barrier, so that they arrive while
       // the slower waves still walk their trees.  The weight registers are not kept across
       // the update below, which needs them.

@@ -8,6 +8,9 @@ step.  metric = MCTS simulations/s (B*S node expansions per step), whole job.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher and with N > 1 it launches itself: the parent starts the N ranks as a
+torch.distributed.run child (before it touches the GPU itself) and exits with the child's code.
+
 Lanes are independent, so ranks shard them with no data-path collective (weak
 scaling: B lanes per GPU); the only collectives are the timing barrier and the
 max-over-ranks of the elapsed time.
@@ -15,6 +18,8 @@ max-over-ranks of the elapsed time.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -44,7 +49,23 @@ def parse():
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="all ranks share cuda:0 and reduce over gloo (checks the N > 1 code path "
                         "on a one-GPU box; not a measurement)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="launcher, process group (gloo), barriers and reductions only, no GPU work "
+                        "(checks the N > 1 plumbing on a machine without GPUs; not a measurement)")
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher's environment: run the N ranks as a
+    torch.distributed.run child process and exit with its code.  Called before anything in this
+    process initialises the GPU; nothing is exec'ed."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def make_networks(env_id, seed, device):
@@ -90,7 +111,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
     collected separately under rocprofv3 with the headline workload), or None."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"))).get(
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"))).get(
             kernel + "_bytes_per_launch")
     except Exception:
         return None
@@ -99,7 +120,7 @@ def pmc_traffic(kernel):
 def pmc_mfma_util(kernel):
     """Matrix-pipe busy share of `kernel` from the committed SQ counter pass, or None."""
     try:
-        ks = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_counters.json")))["kernels"]
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))["kernels"]
         return next((round(v["mfma_util"], 4) for k, v in ks.items() if kernel in k), None)
     except Exception:
         return None
@@ -129,42 +150,77 @@ def tree_kernel_roofline(B, S, A, device, reps=5):
     t = float(np.mean(times))
     alg_bytes = sum_depth * (24 * A + 56) + B * S * (4 * A + 32)
     achieved = alg_bytes / t / 1e9
-    return {"kernel": "k_search_coop_injected", "bound": "hbm", "achieved": round(achieved, 2),
+    return {"kernel": "k_search_wave_injected", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
-            "traffic": pmc_traffic("k_search_coop_injected"), "ms_per_launch": round(t * 1e3, 4),
+            "traffic": pmc_traffic("k_search_wave_injected"), "ms_per_launch": round(t * 1e3, 4),
             "mean_depth": round(sum_depth / (B * S), 3),
             "sims_per_s": round(B * S / t, 1)}
 
 
-def cpu_baseline(env_id, S, lanes, threads):
-    """The plain-C restatement (oracle/) of the same fused search, on `threads` host
-    threads over `lanes` lanes of the same synthetic workload."""
+def cpu_baseline(env_id, S, lanes, threads, runs=5):
+    """The plain-C restatement (oracle/, built -O3 for x86-64-v3) of the same fused search, on
+    `threads` host threads over `lanes` lanes of the same synthetic workload: one warm-up run,
+    then the median of `runs` timed runs."""
     from oracle import runners
     per = max(1, lanes // threads)
     cases = [runners.synthetic_case("gumbel", B=per, S=S, K=1, seed=100 + i, env_id=env_id)
              for i in range(threads)]
-    t0 = time.perf_counter()
-    workers = [threading.Thread(target=runners.run_policy_c, args=(c,)) for c in cases]
-    for w in workers:
-        w.start()
-    for w in workers:
-        w.join()
-    dt = time.perf_counter() - t0
+
+    def once():
+        t0 = time.perf_counter()
+        workers = [threading.Thread(target=runners.run_policy_c, args=(c,)) for c in cases]
+        for w in workers:
+            w.start()
+        for w in workers:
+            w.join()
+        return time.perf_counter() - t0
+
+    once()
+    times = sorted(once() for _ in range(runs))
+    dt = times[len(times) // 2]
     n = per * threads
     return {"value": round(n * S / dt, 1), "unit": "simulations/s", "cores": threads, "kind": "port",
-            "sample": f"{n} lanes x {S} simulations of the same fused CartPole Gumbel search "
-                      f"(plain-C checker, {threads} threads), {dt:.1f} s",
+            "sample": f"{n} lanes x {S} simulations of the same fused {env_id} Gumbel search "
+                      f"(plain-C checker, gcc -O3 x86-64-v3, {threads} threads): median of {runs} runs "
+                      f"after one warm-up, {dt:.2f} s each ({sum(times):.1f} s in all)",
             "env_steps_per_s": round(n / dt, 2)}
+
+
+def dry_run(args, rank, world):
+    """The multi-rank plumbing without a GPU: gloo group, the two barriers, max / sum over ranks,
+    one JSON line from rank 0."""
+    from alphazero_amd import parallel
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    shard = parallel.shard_lanes(args.batch, rank, world, key=1000, weak=True)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    total = parallel.sum_over_ranks(shard.lanes * args.sims * args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "MCTS simulations/s", "value": round(total / elapsed, 1),
+                          "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "data": "none"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
     from alphazero_amd import parallel
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank, world, local = parallel.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run "
-                             "(--nproc-per-node must equal --gpus)")
+        raise SystemExit(f"the launcher started {world} rank(s) but --gpus is {args.gpus}: "
+                         "--nproc-per-node must equal --gpus")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.rehearse_on_one_gpu:
         local = 0
@@ -219,11 +275,11 @@ def main():
                        "lanes_per_gpu": B, "num_simulations": S, "max_num_considered_actions": 16,
                        "parallelism": f"lanes sharded over {world} GPU(s), no data-path collective"},
             "env_steps_per_s": round(total_sims / S / elapsed, 1),
-            "roofline": {"kernel": "k_search_fused", "bound": "mfma", "achieved": round(achieved, 3),
+            "roofline": {"kernel": "k_search_fused_wave", "bound": "mfma", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
-                         "traffic": pmc_traffic("k_search_fused"),
-                         "mfma_util_pmc": pmc_mfma_util("k_search_fused_coop"),
+                         "traffic": pmc_traffic("k_search_fused_wave"),
+                         "mfma_util_pmc": pmc_mfma_util("k_search_fused_wave"),
                          "ms_per_launch": round(kt * 1e3, 4),
                          "mean_depth": round(sum_depth / (B * S), 3)},
         }
@@ -231,7 +287,7 @@ def main():
             line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)
-                lanes = args.cpu_lanes or 512 * threads  # ~10-15 s of wall time
+                lanes = args.cpu_lanes or 192 * threads  # six runs, ~15 s of wall time in all
                 line["cpu_baseline"] = cpu_baseline(args.env, S, lanes, threads)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -32,14 +32,14 @@ def test_algorithmic_work_constants():
 
 
 def test_committed_profile_summaries_are_readable():
-    t = bench.pmc_traffic("k_search_fused")
+    t = bench.pmc_traffic("k_search_fused_wave")
     assert t is not None and 1e8 < t < 1e10
-    assert bench.pmc_traffic("k_search_coop_injected") is not None
-    u = bench.pmc_mfma_util("k_search_fused_coop")
+    assert bench.pmc_traffic("k_search_wave_injected") is not None
+    u = bench.pmc_mfma_util("k_search_fused_wave")
     assert u is not None and 0.05 < u < 1.0
-    stats = open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv")).read()
-    assert "k_search_fused_coop" in stats and "k_search_coop_injected" in stats
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_under_rocprof.log")).read().strip().splitlines()[-1]
+    stats = open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")).read()
+    assert "k_search_fused_wave" in stats and "k_search_wave_injected" in stats
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_under_rocprof.log")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
@@ -47,3 +47,27 @@ def test_committed_profile_summaries_are_readable():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     assert "workload" in d["config"] and d["vs_baseline"] is None
+
+
+def test_self_launch_runs_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (as a child process,
+    before anything touches a GPU) and rank 0 prints the one JSON line; --dry-run keeps the GPU
+    work out so that the plumbing runs here."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--steps", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] > 0
+
+
+def test_launcher_and_flag_must_agree(monkeypatch):
+    import pytest
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    with pytest.raises(SystemExit):
+        bench.main()

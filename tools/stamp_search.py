@@ -22,13 +22,15 @@ lib = nat.lib()
 buf = np.zeros((64, 16), np.int64)
 lib.az_debug_read_sim_stamps.argtypes = [C.c_void_p]
 lib.az_debug_read_sim_stamps(buf.ctypes.data_as(C.c_void_p))
-names = ["walk", "env+rows", "barrier", "MLP", "update"]
+names = ["walk", "leaf+emb", "env", "obs", "rows", "prime", "barrier", "MLP", "update"]
+order = [0, 1, 6, 7, 8, 9, 2, 3, 4]
 print("sim   total | " + " ".join(f"{n:>8}" for n in names))
-tot_sum = np.zeros(6)
+tot_sum = np.zeros(len(names) + 1)
 for sim in range(min(S, 64)):
     row = buf[sim]
     nxt = buf[sim + 1][0] if sim + 1 < min(S, 64) else row[5]
-    d = [int(row[i + 1] - row[i]) for i in range(4)] + [int(nxt - row[4])]
+    pts = [row[i] for i in order] + [nxt]
+    d = [int(pts[i + 1] - pts[i]) for i in range(len(names))]
     tot_sum += np.array([int(nxt - row[0])] + d)
     print(f"{sim:3d} {int(nxt - row[0]):7d} | " + " ".join(f"{x:8d}" for x in d))
 print("mean", " ".join(f"{x:8.0f}" for x in tot_sum / min(S, 64)))
