@@ -118,8 +118,13 @@ class Env:
         return State(**new)
 
     def step_(self, st, action):
-        """In-place variant of `step` (no allocation): updates the tensors of `st`."""
+        """In-place variant of `step` (no allocation): updates the tensors of `st`.  `action` must
+        already be what the kernel reads, int32 [B] contiguous (it is not converted here, which would
+        allocate): any other integer width would be read as interleaved 32-bit words."""
         B = st.state.shape[0]
+        if action.dtype != torch.int32 or not action.is_contiguous() or action.shape != (B,):
+            raise TypeError(f"step_ needs a contiguous int32 action tensor of shape [{B}], got "
+                            f"{action.dtype} {tuple(action.shape)}")
         nat.check(nat.lib().az_real_env_step(
             self.code, B, self.episode_length, nat.ptr(st.state), nat.ptr(st.time),
             nat.ptr(st.obs), nat.ptr(st.real_obs), nat.ptr(st.reward), nat.ptr(st.done),

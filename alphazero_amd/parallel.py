@@ -30,6 +30,21 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
+def trainer_ranks():
+    """(rank, world, local_rank) for a data-parallel learner: the process group decides, and a
+    launcher environment that announces several ranks without an initialised group is an error --
+    every collective would silently be the identity and the replicas would drift apart while
+    their steps are still counted as one job."""
+    import torch.distributed as dist
+    rank, world, local = env_rank()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), local
+    if world > 1:
+        raise RuntimeError(f"WORLD_SIZE={world} but torch.distributed is not initialised: call "
+                           "torch.distributed.init_process_group() before building the Trainer")
+    return 0, 1, local
+
+
 def shard_lanes(num_envs, rank, world, key=0, *, weak=False):
     """Strong scaling (`weak=False`): `num_envs` global lanes split as the reference does,
     `num_envs // world` per rank, which requires divisibility (alphazero.py:893, 1436).

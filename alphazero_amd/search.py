@@ -220,7 +220,10 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
                                       nat.ptr(nxt), nat.ptr(sum_depth), stream))
             pidx = parent.long()
             emb = tree_map(lambda x: x[lanes, pidx], embeddings)  # search.py:222-223
-            step, new_emb = recurrent_fn(params, expand_key, action, emb)
+            # sampled_muzero_policy wraps the recurrent_fn and hands it the first half of
+            # split(expand_key) (policies.py:557); the other policies pass expand_key itself
+            rf_key = prng.split(expand_key, 2)[0] if d.variant == nat.VARIANT_SAMPLED else expand_key
+            step, new_emb = recurrent_fn(params, rf_key, action, emb)
             sl = _f32(step.prior_logits, "recurrent_fn prior_logits")
             sv = _f32(step.value, "recurrent_fn value").reshape(B, -1)
             sr = _f32(step.reward, "recurrent_fn reward")

@@ -23,28 +23,32 @@ from .qtransforms import qtransform_by_parent_and_siblings, qtransform_completed
 
 @dataclasses.dataclass
 class Config:
-    """The hyper-parameters of alphazero.py:37-100 that the training step reads."""
-    env_id: str = "CartPole-v1"
-    seed: int = 0
-    num_envs: int = 64
+    """The hyper-parameters of alphazero.py:37-100 that the training step reads, with the
+    reference's values as defaults (tests and benchmarks pass their own, smaller ones).
+    `policy` and `num_samples` have no Config entry in the reference: its actor_step calls
+    sampled_muzero_policy (alphazero.py:354) without num_samples, i.e. with the policy's
+    default of 100 (mctx_dist/_src/policies.py:131)."""
+    env_id: str = "Acrobot-v1"
+    seed: int = 20
+    num_envs: int = 16
     episode_length: int = 500
-    unroll_length: int = 8
-    num_simulations: int = 32
+    unroll_length: int = 128
+    num_simulations: int = 30
     policy: str = "sampled"            # "sampled" (alphazero.py:354), "muzero", "gumbel"
-    num_samples: int = 16
+    num_samples: int = 100
     max_num_considered_actions: int = 16
     policy_hidden: tuple = (32, 32, 32, 32)
     value_hidden: tuple = (256, 256, 256, 256, 256)
     num_atoms: int = 1
     qr_kappa: float = 1.0
-    use_gae: bool = False
+    use_gae: bool = True
     gae_lambda: float = 0.95
     n_step_n: int = 5
     n_step_gamma: float = 0.99
-    max_replay_size: int = 1 << 16
-    min_replay_size: int = 0
+    max_replay_size: int = 8192
+    min_replay_size: int = 8192
     replay_buffer_batch_size: int = 128
-    num_minibatches: int = 4
+    num_minibatches: int = 128
     update_epochs: int = 1
     per_alpha: float = 0.0
     per_importance_sampling: bool = True
@@ -61,8 +65,11 @@ class Config:
 class Trainer:
     def __init__(self, cfg, device=None):
         self.cfg = cfg
-        self.rank, self.world, local = parallel.env_rank()
+        self.rank, self.world, local = parallel.trainer_ranks()
         self.device = torch.device("cuda", local) if device is None else torch.device(device)
+        if self.device.type == "cuda":
+            # the native launches go to the CURRENT device's stream: make it this rank's
+            torch.cuda.set_device(self.device)
         shard = parallel.shard_lanes(cfg.num_envs, self.rank, self.world, key=cfg.seed)
         self.lanes = shard.lanes
         self.key = shard.key
@@ -102,6 +109,7 @@ class Trainer:
     def actor_step(self, key, deterministic=False):
         """alphazero.py:287-403: search on the current states, act, step the environment."""
         cfg, st = self.cfg, self.env_state
+        _, _, key = prng.split(key, 3)   # key, logits_rng, search_rng (:298); the search takes the third
         logits, value = self.model.forward(st.obs)
         root = RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
         if cfg.policy == "gumbel":
@@ -134,7 +142,7 @@ class Trainer:
         """alphazero.py:406-430: dict of [T, B, ...] tensors."""
         steps = []
         for _ in range(length):
-            key, sub = prng.split(key, 2)[1], prng.split(key, 2)[0]
+            sub, key = prng.split(key, 2)    # current_key, next_key (:422)
             self.env_state, tr = self.actor_step(sub)
             steps.append(tr)
         return {k: torch.stack([s[k] for s in steps], 0) for k in steps[0]}
@@ -149,10 +157,9 @@ class Trainer:
             return L.compute_gae(**kw, lambda_=cfg.gae_lambda, discount=cfg.n_step_gamma)
         return L.n_step_bootstrapped_targets(**kw, n=cfg.n_step_n, gamma=cfg.n_step_gamma)
 
-    def collect(self, key):
+    def collect(self, k_unroll, k_boot):
         """alphazero.py:1104-1151: unroll, bootstrap search, targets, priorities, insert."""
         cfg = self.cfg
-        k_unroll, k_boot = prng.split(key, 2)
         data = self.generate_unroll(k_unroll, cfg.unroll_length)
         saved = self.env_state
         _, boot = self.actor_step(k_boot)       # the extra search only provides the bootstrap value
@@ -172,8 +179,10 @@ class Trainer:
     def training_step(self):
         """alphazero.py:1092-1183."""
         cfg = self.cfg
-        self.key, k_collect = prng.split(self.key, 2)
-        flat = self.collect(k_collect)
+        # key_sgd, key_generate_unroll, key_bootstrap, reanalyze_key, new_key (:1097); the
+        # minibatch permutation draws from a torch generator instead of key_sgd
+        _, k_unroll, k_boot, _, self.key = prng.split(self.key, 5)
+        flat = self.collect(k_unroll, k_boot)
         if cfg.normalize_observations:
             self.stats.update(flat["observation"])
         mean, std = self.stats.mean, self.stats.std
@@ -199,8 +208,8 @@ class Trainer:
     def prefill(self):
         """alphazero.py:1224-1296: collect without learning until min_replay_size rows."""
         while self.replay.size(self.buffer_state) * self.world < self.cfg.min_replay_size:
-            self.key, k = prng.split(self.key, 2)
-            self.collect(k)
+            k_unroll, k_boot, self.key = prng.split(self.key, 3)    # alphazero.py:1229
+            self.collect(k_unroll, k_boot)
 
     def evaluate(self, num_steps):
         """alphazero.py:433-508 in short: greedy actions, mean reward per step and the number

@@ -63,3 +63,18 @@ def test_shard_lanes_rules():
     with pytest.raises(ValueError):
         parallel.shard_lanes(8, 4, 4)
     assert parallel.max_over_ranks(3.5) == 3.5 and parallel.sum_over_ranks(2) == 2.0
+
+
+def test_trainer_refuses_a_launcher_environment_without_a_process_group(monkeypatch):
+    """WORLD_SIZE > 1 without torch.distributed initialised would make every collective of the
+    learner a silent identity: the trainer's rank lookup raises instead."""
+    import pytest
+    from alphazero_amd import parallel
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    with pytest.raises(RuntimeError, match="not initialised"):
+        parallel.trainer_ranks()
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    assert parallel.trainer_ranks()[:2] == (0, 1)

@@ -64,7 +64,7 @@ def main():
             tr.training_step()
         # shares: time the collection alone, then whole steps
         k = (0, 12345)
-        _, t_collect = timed(lambda: tr.collect(k), tr.device)
+        _, t_collect = timed(lambda: tr.collect(k, k), tr.device)
         m = tr.train(args.steps)
         step_s = cfg.unroll_length * cfg.num_envs / m["training/sps"]
         if rank == 0:

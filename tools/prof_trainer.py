@@ -27,10 +27,10 @@ print("  actor_post          %.3f ms" % T(lambda: policies.actor_post(out.search
 a, sv, lp = policies.actor_post(out.search_tree, out.action_weights, out.action, logits)
 print("  env.step            %.3f ms" % T(lambda: tr.env.step(st, a)))
 print("generate_unroll(8)    %.3f ms" % T(lambda: tr.generate_unroll(k, 8), 3))
-print("collect               %.3f ms" % T(lambda: tr.collect(k), 3))
+print("collect               %.3f ms" % T(lambda: tr.collect(k, k), 3))
 print("training_step         %.3f ms" % T(lambda: tr.training_step(), 3))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
-for _ in range(3): tr.collect(k)
+for _ in range(3): tr.collect(k, k)
 torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
