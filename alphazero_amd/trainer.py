@@ -69,6 +69,8 @@ class Trainer:
         self.device = torch.device("cuda", local) if device is None else torch.device(device)
         if self.device.type == "cuda":
             # the native launches go to the CURRENT device's stream: make it this rank's
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
             torch.cuda.set_device(self.device)
         shard = parallel.shard_lanes(cfg.num_envs, self.rank, self.world, key=cfg.seed)
         self.lanes = shard.lanes

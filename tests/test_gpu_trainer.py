@@ -14,7 +14,8 @@ def test_training_steps_run_and_learn_signal(policy, use_gae, atoms, per_alpha):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from alphazero_amd.trainer import Config, Trainer
-    cfg = Config(num_envs=64, unroll_length=6, num_simulations=16, policy=policy, use_gae=use_gae,
+    cfg = Config(env_id="CartPole-v1", num_envs=64, unroll_length=6, num_simulations=16, policy=policy,
+                 use_gae=use_gae,
                  num_atoms=atoms, per_alpha=per_alpha, max_replay_size=2048,
                  replay_buffer_batch_size=32, num_minibatches=4, value_hidden=(64, 64),
                  policy_hidden=(32, 32), num_samples=8)
@@ -47,7 +48,8 @@ def _dp_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from alphazero_amd.trainer import Config, Trainer
-        cfg = Config(num_envs=64, unroll_length=4, num_simulations=8, policy="gumbel",
+        cfg = Config(env_id="CartPole-v1", num_envs=64, unroll_length=4, num_simulations=8, policy="gumbel",
+                     use_gae=False,
                      max_replay_size=2048, replay_buffer_batch_size=32, num_minibatches=2,
                      value_hidden=(64, 64), policy_hidden=(32, 32), per_alpha=0.6)
         tr = Trainer(cfg, device="cuda:0")
