@@ -95,6 +95,8 @@ SIGNATURES = {
     "az_replay_insert": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _I, _P]),
     "az_replay_sample_prioritized": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _K2, _F,
                                                _I, _P, _P, _P]),
+    "az_replay_sample_prioritized_noalloc": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState),
+                                                       _K2, _F, _I, _P, _P, _P]),
     "az_replay_sample_uniform": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _K2, _I, _P,
                                            _P, _P]),
     "az_replay_set_priorities": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P, _P, _I,

@@ -7,6 +7,8 @@
 // order of az_replay.h so that the CPU checker reproduces every bit.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "az_host.h"
 #include "az_math.h"
 #include "../../include/az_replay.h"
@@ -289,12 +291,10 @@ __global__ void k_replay_gather(az_replay r, int head, const int32_t* __restrict
   }
 }
 
-extern "C" int az_replay_sample_prioritized(const az_replay* r, const az_replay_state* st,
-                                            const uint32_t sample_key[2], float beta, int32_t bs,
-                                            int32_t* out_idx, float* out_batch, void* stream) {
-  if (int rc = az_check_replay(r, st)) return rc;
-  if (!sample_key || bs < 1 || !out_idx || !out_batch)
-    return az_fail(AZ_ERR_INVALID, "bad sample arguments");
+// The sampling pass on a descriptor whose scratch pointers (cum, partial) are set.
+static int az_sample_prioritized_impl(const az_replay* r, const az_replay_state* st,
+                                      const uint32_t sample_key[2], float beta, int32_t bs,
+                                      int32_t* out_idx, float* out_batch, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nc = az_scan_chunks(r->cap);
   float* total = r->partial + 2 * nc;  // sum of the masked priorities
@@ -314,6 +314,68 @@ extern "C" int az_replay_sample_prioritized(const az_replay* r, const az_replay_
   k_replay_gather<<<dim3(bs), dim3(64), 0, s>>>(*r, st->head, out_idx, out_batch);
   AZ_LAUNCH_CHECK();
   return AZ_OK;
+}
+
+extern "C" int az_replay_sample_prioritized(const az_replay* r, const az_replay_state* st,
+                                            const uint32_t sample_key[2], float beta, int32_t bs,
+                                            int32_t* out_idx, float* out_batch, void* stream) {
+  if (int rc = az_check_replay(r, st)) return rc;
+  if (!sample_key || bs < 1 || !out_idx || !out_batch)
+    return az_fail(AZ_ERR_INVALID, "bad sample arguments");
+  return az_sample_prioritized_impl(r, st, sample_key, beta, bs, out_idx, out_batch, stream);
+}
+
+// ---------------------------------------------------------------------------
+// The same sampling pass for callers that cannot allocate: its scratch (the cumulative
+// probabilities and the chunk partial sums) lives in a device array of the library.
+#define AZ_REPLAY_SCRATCH_FLOATS \
+  (AZ_REPLAY_NOALLOC_MAX_CAP + 2 * (AZ_REPLAY_NOALLOC_MAX_CAP / AZ_SCAN_CHUNK + 1) + 8)
+static __device__ __align__(256) float scratch[AZ_REPLAY_SCRATCH_FLOATS];
+
+// Address of `scratch` on the current device.  In host code the array's name is only a handle:
+// the address each GPU holds it at comes from hipGetSymbolAddress, once per device, with that
+// device current.
+#define AZ_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static float* g_scratch_ptr[AZ_MAX_DEVICES];
+
+static int az_replay_scratch(float** out) {
+  int dev = -1;
+  AZ_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AZ_MAX_DEVICES)
+    return az_fail(AZ_ERR_UNSUPPORTED, "device ordinal %d outside [0,%d)", dev, AZ_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    AZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return az_fail(AZ_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return AZ_OK;
+}
+
+extern "C" int az_replay_sample_prioritized_noalloc(const az_replay* r, const az_replay_state* st,
+                                                    const uint32_t sample_key[2], float beta,
+                                                    int32_t bs, int32_t* out_idx, float* out_batch,
+                                                    void* stream) {
+  if (!r || !st) return az_fail(AZ_ERR_INVALID, "null replay descriptor or state");
+  if (r->cap > AZ_REPLAY_NOALLOC_MAX_CAP)
+    return az_fail(AZ_ERR_UNSUPPORTED,
+                   "az_replay_sample_prioritized_noalloc holds scratch for at most %d rows, the queue has %d: "
+                   "use az_replay_sample_prioritized with caller-provided scratch",
+                   AZ_REPLAY_NOALLOC_MAX_CAP, r->cap);
+  float* base = nullptr;
+  if (int rc = az_replay_scratch(&base)) return rc;
+  az_replay rr = *r;  // the caller's cum / partial are not used (they may be null)
+  rr.cum = base;
+  rr.partial = base + AZ_REPLAY_NOALLOC_MAX_CAP;
+  if (int rc = az_check_replay(&rr, st)) return rc;
+  if (!sample_key || bs < 1 || !out_idx || !out_batch)
+    return az_fail(AZ_ERR_INVALID, "bad sample arguments");
+  // every word of the scratch that the pass reads is written by it first (chunk totals and
+  // offsets, cum[0, cap), the total) or cleared by it (the running maximum of the weights)
+  return az_sample_prioritized_impl(&rr, st, sample_key, beta, bs, out_idx, out_batch, stream);
 }
 
 extern "C" int az_replay_sample_uniform(const az_replay* r, const az_replay_state* st,

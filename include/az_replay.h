@@ -71,6 +71,19 @@ int az_replay_sample_prioritized(const az_replay* r, const az_replay_state* st,
                                  const uint32_t sample_key[2], float beta, int32_t bs,
                                  int32_t* out_idx, float* out_batch, void* stream);
 
+/* No counterpart in the reference.  The same pass as az_replay_sample_prioritized for callers
+ * that cannot allocate or own scratch memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): r->cum and r->partial are ignored (they may be
+ * NULL) and the pass works in a device array inside the library instead, which holds scratch
+ * for queues of at most AZ_REPLAY_NOALLOC_MAX_CAP rows (about 4 MiB per GPU the library runs
+ * on, kept until the process ends); larger queues are refused with AZ_ERR_UNSUPPORTED.  The
+ * call allocates nothing.  All calls on one GPU share that array: calls that overlap on one GPU
+ * (different streams or threads) race. */
+#define AZ_REPLAY_NOALLOC_MAX_CAP (1 << 20)
+int az_replay_sample_prioritized_noalloc(const az_replay* r, const az_replay_state* st,
+                                         const uint32_t sample_key[2], float beta, int32_t bs,
+                                         int32_t* out_idx, float* out_batch, void* stream);
+
 /* UniformSamplingQueue.sample_internal (replay_buffers.py:260-277): indices =
  * jax.random.randint(sample_key, (bs,), sample_position, insert_position), rows gathered
  * with wrap-around (jnp.take mode='wrap'). */
