@@ -111,6 +111,11 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   md->packed = m->packed;
   md->mean = m->norm_mean;
   md->std = m->norm_std;
+  if (az_mlp_units_per_wave(*md) > AZ_TABLE_UNITS)
+    return az_fail(AZ_ERR_UNSUPPORTED,
+                   "the networks need %d work units per wave, the schedule table holds %d "
+                   "(fewer or narrower layers, or a recurrent_fn in Python through the callback path)",
+                   az_mlp_units_per_wave(*md), AZ_TABLE_UNITS);
   if ((size_t)az_mlp_lds_floats(pk, vk) * 4 > 160 * 1024)
     return az_fail(AZ_ERR_UNSUPPORTED, "layer widths %d / %d need more than 160 KiB of LDS", pk, vk);
   return AZ_OK;
@@ -154,13 +159,14 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   MlpLds s(lds, md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   az_stage_inputs(md, s, tid, blockDim.x);
+  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
-  az_forward_tile<AZ_MLP_WAVES, false, false>(md, s, wave, lane, regs);
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
+  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   MlpLds s(lds, md.pol_kp, md.val_kp);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   az_stage_inputs(md, s, tid, blockDim.x);
+  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) {
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   }
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
-  az_forward_tile<AZ_MLP_WAVES, false, false>(md, s, wave, lane, regs);
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
+  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
   const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   uint32_t r0 = d.key[0], r1 = d.key[1];
   long long depth_sum = 0;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
       az_store_obs(md, s, tid, o.obs);
     }
     __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES, true, true>(md, s, wave, lane, regs);
+    az_forward_tile<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
     if (active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) l.es[(size_t)node * 4 + i] = st.s[i];
@@ -421,12 +428,12 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       // The first unit's weights are requested before the barrier, so that they arrive while
       // the slower waves still walk their trees.  The weight registers are not kept across
       // the update below, which needs them.
-      az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+      az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
     }
-    az_forward_tile<AZ_MLP_WAVES, true, false>(md, s, wave, lane, regs);
+    az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
     AZ_SIM_STAMP(4);
     {
       Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);

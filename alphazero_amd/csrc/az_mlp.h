@@ -157,8 +157,16 @@ struct MlpUnit {
   int ap_off, in_stride, kpq, nkb;      // A operands of the pair: LDS offset, row stride, Kp / 4
   int ap2_off, in_stride2, kpq2, nkb2;  // A operands of the rider
   int phase, idx, round, flags;
-  int pad[2];
+  int bars;  // phase barriers the wave passes after this unit (0: its next unit is in the same phase)
+  int pad;
 };
+
+// What the refills need to know about the unit AFTER the running one.
+struct MlpPre {
+  const az_f32x4 *w0, *w1, *w2;
+  int nkb, nkb2;
+};
+static_assert(sizeof(MlpPre) == 8 * 4, "MlpPre is read as 8 words");
 static_assert(sizeof(MlpUnit) == AZ_UNIT_WORDS * 4, "AZ_UNIT_WORDS must match MlpUnit");
 
 struct PhaseShape {
@@ -168,7 +176,7 @@ struct PhaseShape {
   int n;         // items of the phase
 };
 
-AZ_DEV PhaseShape az_phase_shape(const ModelDev& md, int phase) {
+__host__ __device__ inline PhaseShape az_phase_shape(const ModelDev& md, int phase) {
   PhaseShape p;
   const int tv = phase < md.val.n_layers ? md.val.np[phase] >> 4 : 0;
   const int tp = phase < md.pol.n_layers ? md.pol.np[phase] >> 4 : 0;
@@ -213,7 +221,8 @@ AZ_DEV MlpUnit az_mlp_unit(const ModelDev& md, const MlpLds& s, int phase, int i
   u.phase = phase;
   u.idx = idx;
   u.round = round;
-  u.pad[0] = u.pad[1] = 0;
+  u.bars = 0;
+  u.pad = 0;
   const PhaseShape ps = az_phase_shape(md, phase);
   const bool is_val = idx < ps.n_val;
   const MlpLayout& L = is_val ? md.val : md.pol;
@@ -275,40 +284,113 @@ AZ_DEV MlpUnit az_mlp_next_unit(const ModelDev& md, const MlpLds& s, int P, int 
   return az_mlp_no_unit(P);
 }
 
-AZ_DEV int az_mlp_phases(const ModelDev& md) {
+__host__ __device__ inline int az_mlp_phases(const ModelDev& md) {
   return md.pol.n_layers > md.val.n_layers ? md.pol.n_layers : md.val.n_layers;
 }
 
+// Units the busiest wave (wave 0) runs in one pass over both networks; the schedule table
+// holds AZ_TABLE_UNITS per wave, and the host refuses models that need more.
+inline int az_mlp_units_per_wave(const ModelDev& md) {
+  int units = 0;
+  for (int phase = 0; phase < az_mlp_phases(md); ++phase) {
+    const PhaseShape ps = az_phase_shape(md, phase);
+    for (int idx = 0; idx < ps.n; idx += AZ_MLP_WAVES) {
+      const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
+      units += ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
+    }
+  }
+  return units;
+}
+
 // Writes the wave's unit sequence into the LDS table (every wave calls it; the caller
-// places a workgroup barrier before the first az_forward_tile).
+// places a workgroup barrier before the first az_forward_tile).  tab_n[wave] = number of
+// units, tab_n[NWAVES + wave] = phase barriers the wave passes before its first unit.
 template <int NWAVES>
 AZ_DEV void az_mlp_table_build(const ModelDev& md, const MlpLds& s, int wave, int lane) {
   const int P = az_mlp_phases(md);
   int n = 0;
   MlpUnit u = az_mlp_next_unit<NWAVES>(md, s, P, 0, 0, 0, true, wave);
+  const int lead = u.phase;  // P when the wave has no unit at all
   while (u.flags & AZ_U_VALID) {
+    const MlpUnit nx = az_mlp_next_unit<NWAVES>(md, s, P, u.phase, u.idx, u.round, false, wave);
+    u.bars = nx.phase - u.phase;  // past the last unit: nx.phase == P
     if (n < AZ_TABLE_UNITS && lane == 0)
       *reinterpret_cast<MlpUnit*>(s.tab + (size_t)(wave * AZ_TABLE_UNITS + n) * AZ_UNIT_WORDS) = u;
     ++n;
-    u = az_mlp_next_unit<NWAVES>(md, s, P, u.phase, u.idx, u.round, false, wave);
+    u = nx;
   }
-  if (lane == 0) s.tab_n[wave] = n <= AZ_TABLE_UNITS ? n : -1;
+  if (lane == 0) {
+    s.tab_n[wave] = n <= AZ_TABLE_UNITS ? n : 0;
+    s.tab_n[NWAVES + wave] = n <= AZ_TABLE_UNITS ? lead : P;
+  }
 }
 
-// Descriptor `i` of the wave out of the table, in scalar registers: lane k reads word
-// k (one LDS access for the whole descriptor), then each word is broadcast from its lane.
-AZ_DEV MlpUnit az_mlp_table_fetch(const MlpLds& s, int wave, int i, int lane) {
-  static_assert(AZ_UNIT_WORDS <= 64, "one word per lane");
+// One LDS access for everything a wave needs at the start of unit `i`: lane k < AZ_UNIT_WORDS
+// reads word k of descriptor i, lanes 40 .. 47 the refill fields (MlpPre) of descriptor `ipre`.
+#define AZ_PRE_LANE0 40
+AZ_DEV uint32_t az_mlp_table_read(const MlpLds& s, int wave, int i, int ipre, int lane) {
+  static_assert(AZ_UNIT_WORDS <= AZ_PRE_LANE0 && AZ_PRE_LANE0 + 8 <= 64, "one word per lane");
+  const int pw = lane - AZ_PRE_LANE0;  // 0..5: the three weight pointers, 6: nkb, 7: nkb2
+  const int pre_word = pw < 6 ? pw : (pw == 6 ? (int)(offsetof(MlpUnit, nkb) / 4) : (int)(offsetof(MlpUnit, nkb2) / 4));
+  int word = 0;
+  if (lane < AZ_UNIT_WORDS) word = i * AZ_UNIT_WORDS + lane;
+  if (pw >= 0 && pw < 8) word = ipre * AZ_UNIT_WORDS + pre_word;
+  return s.tab[wave * (AZ_TABLE_UNITS * AZ_UNIT_WORDS) + word];
+}
+
+// The words broadcast into scalar registers.  The weight pointers of the running unit are
+// not needed (its weights are in registers already) and are left zero.
+AZ_DEV void az_mlp_table_decode(uint32_t mine, MlpUnit& u, MlpPre& pre) {
   union {
     MlpUnit u;
     uint32_t w[AZ_UNIT_WORDS];
   } x;
-  const uint32_t* src = s.tab + (size_t)(wave * AZ_TABLE_UNITS + i) * AZ_UNIT_WORDS;
-  const uint32_t mine = src[lane < AZ_UNIT_WORDS ? lane : 0];
 #pragma unroll
-  for (int k = 0; k < AZ_UNIT_WORDS; ++k) x.w[k] = __builtin_amdgcn_readlane(mine, k);
-  return x.u;
+  for (int k = 0; k < AZ_UNIT_WORDS; ++k) x.w[k] = k < 6 ? 0u : (uint32_t)__builtin_amdgcn_readlane(mine, k);
+  u = x.u;
+  union {
+    MlpPre p;
+    uint32_t w[8];
+  } y;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) y.w[k] = __builtin_amdgcn_readlane(mine, AZ_PRE_LANE0 + k);
+  pre = y.p;
 }
+
+#ifdef AZ_WATCHDOG
+// Diagnostic build only (-DAZ_WATCHDOG): every loop that contains a barrier checks a cycle
+// budget; a wave past the budget logs where it is and ends, so the kernel cannot hang.
+__device__ int az_wd_log[64][8];
+__device__ int az_wd_n;
+#define AZ_WD_LIMIT (1ll << 28)
+AZ_DEV void az_wd_check(const float* t0_slot, int site, int a, int b, int c, int d) {
+  // wave-uniform on purpose (scalar compare and branch): the check must not change how the
+  // surrounding code waits for its memory operations
+  const int lo = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t0_slot)[0]);
+  const int hi = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t0_slot)[1]);
+  const long long t0 = ((long long)hi << 32) | (unsigned)lo;
+  if ((long long)__builtin_amdgcn_s_memtime() - t0 > AZ_WD_LIMIT) {
+    if ((threadIdx.x & 63) == 0) {
+      const int k = atomicAdd(&az_wd_n, 1);
+      if (k < 64) {
+        az_wd_log[k][0] = blockIdx.x;
+        az_wd_log[k][1] = threadIdx.x >> 6;
+        az_wd_log[k][2] = site;
+        az_wd_log[k][3] = a;
+        az_wd_log[k][4] = b;
+        az_wd_log[k][5] = c;
+        az_wd_log[k][6] = d;
+      }
+    }
+    __builtin_amdgcn_endpgm();
+  }
+}
+#define AZ_WD(slot, site, a, b, c, d) az_wd_check(slot, site, a, b, c, d)
+#else
+#define AZ_WD(slot, site, a, b, c, d) \
+  do {                                \
+  } while (0)
+#endif
 
 // Workgroup barrier that publishes LDS writes but leaves the weight prefetch (global
 // loads into registers) in flight: a plain __syncthreads() would drain it.
@@ -360,7 +442,7 @@ AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& ac
 // the prefetch distance is a whole unit, up to 32 KiB in flight per wave).  There is
 // one copy of this loop on purpose: a second instantiation (say, for single-tile
 // units) makes the register allocator keep two sets of weight slots and spill.
-AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, az_f32x4& acc0,
+AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
                              az_f32x4& acc1, az_f32x4& acc2, const float* ap, const float* ap2,
                              int lane) {
   const int nk = next.nkb - 1, nk2 = next.nkb2 > 0 ? next.nkb2 - 1 : 0;
@@ -415,7 +497,7 @@ AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, 
   }
 }
 
-AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, az_f32x4& acc0,
+AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
                             az_f32x4& acc1, float* lds_base, int lane, int wave_, int& stamp_i) {
   const bool two = u.flags & AZ_U_TWO, last = u.flags & AZ_U_LAST, rider = u.flags & AZ_U_RIDER;
   if (u.flags & AZ_U_FIRST) {
@@ -451,25 +533,17 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpUnit& next, MlpRegs& R, a
   if (two) az_mlp_tile_epilogue(u.o0, 16, acc1, bias1, lds_base, lane);
 }
 
-// The wave's unit `i`: from the LDS table (TABLE and the table holds this wave's
-// sequence) or recomputed from the previous unit.
-template <int NWAVES, bool TABLE>
-AZ_DEV MlpUnit az_mlp_unit_at(const ModelDev& md, const MlpLds& s, int P, int wave, int lane,
-                              int n_tab, int i, const MlpUnit& prev, bool start) {
-  if (TABLE && n_tab >= 0) return i < n_tab ? az_mlp_table_fetch(s, wave, i, lane) : az_mlp_no_unit(P);
-  return az_mlp_next_unit<NWAVES>(md, s, P, prev.phase, prev.idx, prev.round, start, wave);
-}
-
 // Loads the weights of the wave's first unit; call before az_forward_tile (once, when
 // the calls wrap).
-template <int NWAVES, bool TABLE>
+template <int NWAVES>
 AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
-  const int P = az_mlp_phases(md);
-  const int n_tab = TABLE ? __builtin_amdgcn_readfirstlane(s.tab_n[wave]) : -1;
-  const MlpUnit cur = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, az_mlp_no_unit(P), true);
+  const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
+  if (n_tab <= 0) return;
+  MlpUnit unused;
+  MlpPre cur;
+  az_mlp_table_decode(az_mlp_table_read(s, wave, 0, 0, lane), unused, cur);
   // same order and count as a unit's refills
   const int nk = cur.nkb > 0 ? cur.nkb - 1 : 0, nk2 = cur.nkb2 > 0 ? cur.nkb2 - 1 : 0;
-  if (!(cur.flags & AZ_U_VALID)) return;
 #pragma unroll
   for (int kb = 0; kb < AZ_SLOTS; ++kb) {
     const int kc = kb < nk ? kb : nk;
@@ -483,34 +557,38 @@ AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int 
 }
 
 // Both networks on the 16 rows staged in s.in0 -> s.logits / s.value.  Called by all
-// NWAVES waves with the first unit's weights in R (az_forward_prime); ends with a
-// workgroup barrier (LDS results visible to every thread).  With WRAP the last unit
-// prefetches the first unit's weights again, so the next call needs no priming.
-template <int NWAVES, bool TABLE, bool WRAP>
+// NWAVES waves with the first unit's weights in R (az_forward_prime); every wave passes one
+// workgroup barrier per phase, the last of which makes the results visible to every thread.
+// With WRAP the last unit prefetches the first unit's weights again, so the next call needs
+// no priming.
+template <int NWAVES, bool WRAP>
 AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
-  const int P = az_mlp_phases(md);
-  const int n_tab = TABLE ? __builtin_amdgcn_readfirstlane(s.tab_n[wave]) : -1;
+  const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
+  const int lead = __builtin_amdgcn_readfirstlane(s.tab_n[NWAVES + wave]);
   az_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int stamp_i = 0;
   const int wave_ = wave;
   (void)wave_;
   AZ_STAMP_AT();
-  int ui = 0;
-  MlpUnit cur = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, az_mlp_no_unit(P), true);
-  for (int phase = 0; phase < P; ++phase) {
-    while ((cur.flags & AZ_U_VALID) && cur.phase == phase) {
-      MlpUnit next = az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, ui + 1, cur, false);
-      ++ui;
-      MlpUnit pre = next;  // the unit whose weights the refills fetch (always a valid one)
-      if (!(next.flags & AZ_U_VALID))
-        pre = WRAP ? az_mlp_unit_at<NWAVES, TABLE>(md, s, P, wave, lane, n_tab, 0, cur, true) : cur;
-      AZ_STAMP_AT();
-      az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
-      AZ_STAMP_AT();
-      cur = next;
-    }
-    AZ_STAMP_AT();
+  for (int b = 0; b < lead; ++b) {
+    AZ_WD(s.norm_std + 60, 2, b, lead, n_tab, 0);
     az_lds_barrier();
+  }
+  for (int ui = 0; ui < n_tab; ++ui) {
+    AZ_WD(s.norm_std + 60, 1, ui, n_tab, lead, 0);
+    // the unit whose weights the refills fetch: the next one, or (past the last) the first
+    // one again / this one once more, so that the refill loads always have a valid source
+    const int ipre = ui + 1 < n_tab ? ui + 1 : (WRAP ? 0 : ui);
+    MlpUnit cur;
+    MlpPre pre;
+    az_mlp_table_decode(az_mlp_table_read(s, wave, ui, ipre, lane), cur, pre);
+    AZ_STAMP_AT();
+    az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
+    AZ_STAMP_AT();
+    for (int b = 0; b < cur.bars; ++b) {
+      AZ_WD(s.norm_std + 60, 3, b, cur.bars, ui, n_tab);
+      az_lds_barrier();
+    }
     AZ_STAMP_AT();
   }
 }

@@ -33,12 +33,12 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_probe(ModelDev md, int it
     for (int i = 0; i < md.obs_dim; ++i)
       s.in0[tid * AZ_IN0_STRIDE + az_act_index(i, md.val.kp[0])] = 0.01f * (tid + i + blockIdx.x % 7);
   MlpRegs regs;
-  if (WRAP) az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+  if (WRAP) az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
   float acc = 0.0f;
   for (int it = 0; it < iters; ++it) {
-    if (!WRAP) az_forward_prime<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+    if (!WRAP) az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
     __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES, true, WRAP>(md, s, wave, lane, regs);
+    az_forward_tile<AZ_MLP_WAVES, WRAP>(md, s, wave, lane, regs);
     if (tid < 16) {
       acc += s.value[tid * AZ_MAX_ATOMS] + s.logits[tid * AZ_MAX_ACTIONS];
       s.in0[tid * AZ_IN0_STRIDE] = 0.001f * s.logits[tid * AZ_MAX_ACTIONS];
