@@ -80,7 +80,9 @@ def run_policy_hip(case, path="persistent", literal=False):
             out = mctx.muzero_policy(**common, **kw)
         else:
             out = mctx.sampled_muzero_policy(num_samples=case["num_samples"],
-                                             sample_counts=dev(case["counts"]), **common, **kw)
+                                             sample_counts=dev(case["counts"]),
+                                             sampling_dist_temperature=case.get("sampling_temperature", 1.0),
+                                             **common, **kw)
     torch.cuda.synchronize()
     t = out.search_tree
     res = {f: getattr(t, f).cpu().numpy() for f in INT_FIELDS + FLT_FIELDS}

@@ -335,6 +335,37 @@ def test_full_size_fused_properties(hip):
         assert np.array_equal(out[f][:64], ref[f].reshape(out[f][:64].shape)), f
 
 
+@pytest.mark.parametrize("variant,extra", [("muzero", dict(temperature=0.5)),
+                                           ("muzero", dict(temperature=2.0)),
+                                           ("sampled", dict(temperature=0.25, sampling_temperature=0.5)),
+                                           ("sampled", dict(sampling_temperature=3.0))])
+def test_temperatures_vs_oracle(hip, variant, extra):
+    """temperature (policies.py:118-119) and sampling_dist_temperature (policies.py:546) away
+    from 1: action, action_weights, the root prior and the whole tree against the checker."""
+    case = runners.synthetic_case(variant, B=32, S=16, A=4, K=1, seed=61)
+    case.update(extra)
+    ref = runners.run_policy_c(case)
+    out = hip.run_policy_hip(case, "persistent")
+    hip.assert_same(out, ref)
+
+
+def test_largest_configuration_full_size_properties(hip):
+    """The large-tree stress configuration at full size (16384 lanes x 256 simulations, fused
+    CartPole Gumbel search): structural invariants on every lane, the sequential-halving split,
+    and bit equality of the first 64 lanes with the CPU checker (lanes are independent)."""
+    B, S = 16384, 256
+    case = runners.synthetic_case("gumbel", B=B, S=S, K=1, seed=29, env_id="CartPole-v1")
+    out = hip.run_policy_hip(case, "persistent")
+    check_invariants(out, S)
+    assert (out["children_visits"][:, 0] == S // 2).all()
+    np.testing.assert_allclose(out["action_weights"].sum(-1), 1.0, rtol=1e-6)
+    assert out["sum_depth"] > B * S
+    ref = runners.run_policy_c({**case, "B": 64, **{k: case[k][:64] for k in
+                                ("prior_logits", "value", "root_gumbel", "root_state", "root_time")}})
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS + ("emb_state", "emb_time", "action", "action_weights"):
+        assert np.array_equal(out[f][:64], ref[f].reshape(out[f][:64].shape)), f
+
+
 # ---------------------------------------------------------------- device RNG paths
 def test_default_rng_paths_vs_oracle(hip, oracle):
     """Without injected noise the device threefry streams equal the C checker's."""

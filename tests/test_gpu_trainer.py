@@ -37,6 +37,39 @@ def test_training_steps_run_and_learn_signal(policy, use_gae, atoms, per_alpha):
     assert ev["mean_reward"] > 0
 
 
+@pytest.mark.parametrize("env_id,use_gae", [("Acrobot-v1", False), ("MountainCar-v0", True),
+                                            ("Acrobot-v1", True), ("MountainCar-v0", False)])
+def test_training_steps_on_acrobot_and_mountaincar_with_prioritized_replay(env_id, use_gae):
+    """Acrobot / MountainCar (three actions) with prioritized replay (alpha 0.6, beta 0.4) and
+    n-step or GAE targets: the training step runs end to end on the fused search of those
+    environments, priorities stay positive and finite and are refreshed by the SGD step."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd.trainer import Config, Trainer
+    cfg = Config(env_id=env_id, num_envs=128, unroll_length=6, num_simulations=16, policy="gumbel",
+                 use_gae=use_gae, per_alpha=0.6, per_importance_sampling_beta=0.4, max_replay_size=4096,
+                 min_replay_size=0, replay_buffer_batch_size=64, num_minibatches=4,
+                 value_hidden=(64, 64), policy_hidden=(32, 32), seed=3)
+    tr = Trainer(cfg, device="cuda")
+    before = [p.clone() for p in tr.optimizer.params]
+    m = tr.train(3)
+    assert all(math.isfinite(v) for v in m.values()), m
+    assert m["buffer_current_size"] == 3 * 6 * 128
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.optimizer.params))
+    data = tr.buffer_state.data[:3 * 6 * 128]
+    pri, w = data[:, -2], data[:, -1]
+    assert torch.isfinite(pri).all() and (pri > 0).all() and pri.unique().numel() > 16
+    assert torch.isfinite(w).all() and (w > 0).all() and float(w.max()) <= 1.0
+    assert (data[:, tr.layout["reward"][0]] == -1).all()          # both environments pay -1 per step
+    # three actions: action weights are a distribution over them, actions in range
+    a0, _ = tr.layout["action"]
+    assert set(data[:, a0].unique().tolist()) <= {0.0, 1.0, 2.0}
+    p0, pw = tr.layout["target_policy_probs"]
+    assert pw == 3
+    torch.testing.assert_close(data[:, p0:p0 + pw].sum(-1), torch.ones_like(pri), rtol=1e-5, atol=1e-6)
+
+
 def _dp_worker(rank, world, port, out):
     """One data-parallel rank of the trainer; both ranks share cuda:0 and reduce over gloo
     (on an 8-GPU node the same code runs one rank per GPU over RCCL)."""

@@ -57,6 +57,22 @@ def test_c_vs_numpy_injected(kw):
     assert c["sum_depth"] == n["sum_depth"] or True
 
 
+@pytest.mark.parametrize("variant,extra", [("muzero", dict(temperature=0.5)),
+                                           ("muzero", dict(temperature=2.0)),
+                                           ("sampled", dict(temperature=0.25, sampling_temperature=0.5)),
+                                           ("sampled", dict(sampling_temperature=3.0))])
+def test_c_vs_numpy_temperatures(variant, extra):
+    """policies.py:118-119 (_apply_temperature) and :546 (the sampling distribution's exponent
+    1 - 1/tau) away from their defaults of 1."""
+    case = runners.synthetic_case(variant, B=32, S=16, A=4, K=1, seed=61)
+    case.update(extra)
+    c, n = runners.run_policy_c(case), runners.run_policy_numpy(case)
+    compare_runs(c, n, max_tie_lanes=2)
+    if "sampling_temperature" in extra:   # the sampling temperature reshapes the root prior
+        base = runners.run_policy_c({**case, "sampling_temperature": 1.0})
+        assert not np.array_equal(base["root_prior"], c["root_prior"])
+
+
 @pytest.mark.parametrize("env_id,variant", [("CartPole-v1", "gumbel"), ("CartPole-v1", "muzero"),
                                             ("MountainCar-v0", "muzero"), ("Acrobot-v1", "gumbel"),
                                             ("Acrobot-v1", "sampled")])
