@@ -101,6 +101,7 @@ class Trainer:
         self.buffer_state = self.replay.init(kb, device=self.device)
         self.env_state = self.env.reset(ke, batch_size=self.lanes, device=self.device)
         self.env_steps = 0
+        self.trace = None   # a list here records every actor step's raw inputs and outputs
         self._perm_gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1)
 
     # -------------------------------------------------------------- self-play
@@ -129,6 +130,11 @@ class Trainer:
             out.search_tree, out.action_weights, out.action, logits, deterministic=deterministic)
         obs, real_obs = st.obs.clone(), st.real_obs.clone()
         nst = self.env.step(st, action)
+        if self.trace is not None:
+            self.trace.append(dict(obs=obs, real_obs=real_obs, value=value, action=action,
+                                   action_weights=out.action_weights, search_value=search_value,
+                                   prior_log_prob=log_prob, reward=nst.reward, done=nst.done,
+                                   truncation=nst.truncation, next_real_obs=nst.real_obs))
         ones = torch.ones_like(nst.reward)
         tr = dict(observation=obs, real_obs=real_obs, action=action.float(), reward=nst.reward,
                   discount=1 - nst.done, next_observation=nst.real_obs,
@@ -185,6 +191,11 @@ class Trainer:
         # minibatch permutation draws from a torch generator instead of key_sgd
         _, k_unroll, k_boot, _, self.key = prng.split(self.key, 5)
         flat = self.collect(k_unroll, k_boot)
+        return self.learn(flat)
+
+    def learn(self, flat):
+        """alphazero.py:1153-1183: statistics, sample, SGD, priority refresh."""
+        cfg = self.cfg
         if cfg.normalize_observations:
             self.stats.update(flat["observation"])
         mean, std = self.stats.mean, self.stats.std

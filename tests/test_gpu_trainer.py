@@ -125,3 +125,70 @@ def test_two_rank_trainer_keeps_replicas_identical():
     assert a[6] == b[6] == 2 * 4 * 64                            # statistics merged over both ranks
     assert np.array_equal(a[7], b[7]), np.abs(a[7] - b[7]).max()  # replicas bit-identical
     assert np.array_equal(a[8], b[8])
+
+
+@pytest.mark.parametrize("use_gae,atoms", [(False, 1), (True, 1), (False, 4)])
+def test_training_step_plumbing_vs_restatement(use_gae, atoms):
+    """The assembly of the training step (transition record -> targets -> priorities -> replay rows
+    -> sample -> SGD -> priority refresh with the pre-update networks, alphazero.py:385-403,
+    1104-1180) against its NumPy restatement in float64, with the search outputs and environment
+    transitions of the run injected: rows, priorities and refreshed priorities to 1e-5."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd import learner as L
+    from alphazero_amd import prng
+    from alphazero_amd.trainer import Config, Trainer
+    from oracle import trainer_numpy as tn
+    T, B = 7, 48
+    cfg = Config(env_id="CartPole-v1", num_envs=B, unroll_length=T, num_simulations=8, policy="gumbel",
+                 use_gae=use_gae, num_atoms=atoms, per_alpha=0.6, per_importance_sampling_beta=0.4,
+                 max_replay_size=1024, min_replay_size=0, replay_buffer_batch_size=32, num_minibatches=4,
+                 value_hidden=(64, 64), policy_hidden=(32, 32), episode_length=5, seed=11)
+    tr = Trainer(cfg, device="cuda")
+    # a few plain steps first: non-trivial statistics, episode ends (length 5) inside the unroll
+    tr.train(2)
+    n0 = int(tr.replay.size(tr.buffer_state))
+    tr.trace = []
+    k1, k2, _ = prng.split(tr.key, 3)
+    flat = tr.collect(k1, k2)
+    steps = [{k: v.double().cpu().numpy() for k, v in s.items()} for s in tr.trace]
+    tr.trace = None
+    assert len(steps) == T + 1
+    ref = tn.assemble(steps[:T], steps[T], use_gae=use_gae, gae_lambda=cfg.gae_lambda,
+                      n_step_n=cfg.n_step_n, gamma=cfg.n_step_gamma, per_alpha=cfg.per_alpha)
+    assert float(ref["truncation"].sum()) > 0 and float((1 - ref["discount"]).sum()) > 0
+    ref_rows = tn.rows(ref)
+    got_rows = tr.buffer_state.data[n0:n0 + T * B].double().cpu().numpy()
+    assert got_rows.shape == ref_rows.shape == (T * B, tr.layout["_width"])
+    np.testing.assert_allclose(got_rows[:, :-1], ref_rows[:, :-1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(flat["priority"].double().cpu().numpy(), ref["priority"], rtol=1e-5, atol=1e-7)
+
+    # the learner half: sample, SGD, refresh.  Pre-update networks and statistics are snapshotted.
+    mean0, std0 = tr.stats.mean.double().cpu().numpy(), tr.stats.std.double().cpu().numpy()
+    # (the refresh runs on the self-play model, which holds the statistics of before this step)
+    model_mean, model_std = mean0.copy(), std0.copy()
+    val0 = [(w.detach().double().cpu().numpy(), b.detach().double().cpu().numpy())
+            for w, b in tr.value_layers]
+    before = tr.buffer_state.data.double().cpu().numpy()
+    tr.learn(flat)
+    idx = tr.buffer_state.current_sample_indices.cpu().numpy()
+    after = tr.buffer_state.data.double().cpu().numpy()
+    sampled = before[idx]
+    def col(name, keep_axis=False):
+        o, w = tr.layout[name]
+        x = sampled[:, o:o + w]
+        return x if keep_axis else x[:, 0]
+    batch = dict(observation=col("observation", True), bootstrap_value=col("bootstrap_value", True),
+                 value_prefix_target=col("value_prefix_target"),
+                 bootstrap_discount=col("bootstrap_discount"))
+    ref_pri = tn.refreshed_priorities(batch, val0, model_mean, model_std, cfg.per_alpha)
+    last = {int(i): p for p, i in enumerate(idx)}          # a repeated index keeps its last write
+    rows_i = np.array(sorted(last))
+    want = np.array([ref_pri[last[int(i)]] for i in rows_i])
+    np.testing.assert_allclose(after[rows_i, -2], want, rtol=2e-5, atol=1e-7)
+    untouched = np.setdiff1d(np.arange(after.shape[0]), rows_i)
+    assert np.array_equal(after[untouched, -2], before[untouched, -2])
+    # rows themselves are not modified by the learner
+    assert np.array_equal(after[:, :-2], before[:, :-2])
