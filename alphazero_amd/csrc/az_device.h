@@ -21,14 +21,14 @@
 
 #define AZ_DEV __device__ __forceinline__
 
-// Loops over actions / atoms: fully unrolled for compile-time bounds up to 8 (the
+// Loops over actions / atoms: fully unrolled for compile-time bounds up to 16 (the
 // vectors then live in registers), plain run-time loops for the generic bound.
 // The enclosing function must have `A` (resp. `K`) in scope.
-constexpr int az_uf(int n) { return n <= 8 ? n : 1; }
+constexpr int az_uf(int n) { return n <= 16 ? n : 1; }
 #define AZ_UNROLL_A _Pragma("unroll az_uf(AMAX)")
-#define AZ_TRIP_A (AMAX <= 8 ? AMAX : A)
+#define AZ_TRIP_A (AMAX <= 16 ? AMAX : A)
 #define AZ_UNROLL_K _Pragma("unroll az_uf(KMAX)")
-#define AZ_TRIP_K (KMAX <= 8 ? KMAX : K)
+#define AZ_TRIP_K (KMAX <= 16 ? KMAX : K)
 
 template <int AMAX, int KMAX>
 struct Lane {

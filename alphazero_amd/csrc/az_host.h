@@ -66,7 +66,11 @@ static int az_dispatch_coop(int A, int K, F&& f) {
   } else if (K == 8) {
     if (A == 2) return f.template operator()<2, 8, true>();
     if (A == 3) return f.template operator()<3, 8, true>();
+  } else if (K == 16) {  // 16-atom quantile heads on the built-in environments
+    if (A == 2) return f.template operator()<2, 16, true>();
+    if (A == 3) return f.template operator()<3, 16, true>();
   }
+  if (K > 8) return az_fail(AZ_ERR_UNSUPPORTED, "cooperative search dispatched beyond its bounds");
   return f.template operator()<8, 8, false>();
 #endif
 }

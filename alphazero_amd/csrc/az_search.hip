@@ -213,7 +213,8 @@ static size_t az_wave_lds_bytes(const az_search_desc* d) {
 // `extra_lds_bytes` of other use.
 bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool borrowed) {
   if (d->kernel_form == 1) return false;  // the caller asked for the literal kernels
-  if (d->A > 8 || d->K > 8 || d->S + 1 > 65535) return false;
+  const bool k16 = d->K == 16 && (d->A == 2 || d->A == 3);  // the compile-time 16-atom shapes
+  if (d->A > 8 || (d->K > 8 && !k16) || d->S + 1 > 65535) return false;
   (void)borrowed;
   return az_wave_lds_bytes(d) + extra_lds_bytes <= 160 * 1024;
 }

@@ -28,7 +28,8 @@
 // (NOISY): the form without per-visit noise (Gumbel, or PUCT with the noise disabled) carries
 // none of that code.
 //
-// Applicability: A <= 8, K <= 8 (vectors in registers), N <= 65535 (16-bit node codes).
+// Applicability: A <= 8 and K <= 8, or K = 16 with A = 2 or 3 (vectors in registers);
+// N <= 65535 (16-bit node codes).
 #ifndef AZ_WAVE_H_
 #define AZ_WAVE_H_
 

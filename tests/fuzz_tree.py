@@ -14,7 +14,7 @@ bad = 0
 for i in range(n_cases):
     variant = ["gumbel", "muzero", "sampled"][rng.integers(3)]
     kw = dict(B=int(rng.integers(1, 70)), S=int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 300])),
-              A=int(rng.integers(1, 9)), K=int(rng.choice([1, 1, 2, 8])))
+              A=int(rng.integers(1, 9)), K=int(rng.choice([1, 1, 2, 8, 16])))
     if rng.random() < 0.3:
         kw["max_depth"] = int(rng.integers(1, 6))
     if rng.random() < 0.3:

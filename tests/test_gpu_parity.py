@@ -102,6 +102,10 @@ INJECTED_CASES = [
     dict(variant="muzero", B=8, S=16, A=20, K=12),
     dict(variant="sampled", B=32, S=16, A=4, K=8),
     dict(variant="sampled", B=16, S=24, A=3, K=1, with_invalid=True),
+    # 16-atom quantile heads on the built-in environments' action counts (cooperative form)
+    dict(variant="sampled", B=20, S=24, A=3, K=16),
+    dict(variant="gumbel", B=20, S=40, A=2, K=16),
+    dict(variant="muzero", B=8, S=12, A=5, K=16),    # other shapes with K > 8: literal form
     # smallest shapes: one lane, one simulation, one action; a ragged last workgroup
     dict(variant="gumbel", B=1, S=1, A=2, K=1),
     dict(variant="muzero", B=17, S=1, A=1, K=1),
@@ -200,6 +204,8 @@ FUSED_CASES = [
     ("MountainCar-v0", "muzero", 16, 12, 1, {}),
     ("Acrobot-v1", "gumbel", 16, 12, 1, {}),
     ("Acrobot-v1", "sampled", 16, 12, 8, {}),
+    ("CartPole-v1", "sampled", 20, 40, 16, {}),     # 16-atom value head
+    ("MountainCar-v0", "gumbel", 16, 24, 16, {}),
     ("CartPole-v1", "gumbel", 16, 20, 1, dict(max_depth=3)),
 ]
 
@@ -235,6 +241,7 @@ def test_fused_equals_callback_path(hip):
     dict(variant="muzero", B=40, S=64, A=3, K=2),    # PUCT with per-visit tie-break noise
     dict(variant="sampled", B=24, S=48, A=4, K=1, with_invalid=True),
     dict(variant="muzero", B=16, S=40, A=8, K=1, max_depth=6),
+    dict(variant="sampled", B=12, S=72, A=3, K=16),  # 16 atoms, paths deeper than one pass
 ], ids=_ids)
 def test_literal_and_cooperative_tree_kernels_agree(hip, kw):
     """The literal one-thread-per-lane kernel and the cooperative 32-threads-per-lane kernel
