@@ -165,17 +165,9 @@ AZ_UNROLL_K
   }
   for (int sim = 0; sim < S; ++sim) {
     AZ_TREE_STAMP(0);
-    WavePath wp;
-    if (NOISY)
-      wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
-                                           need_keys ? sim_keys : nullptr);
-    else
-      wp = az_wave_chase_lean(s, h, j, sim, d.max_depth, active);
-    if (j == 0) depth_sum += wp.dep;
-    AZ_TREE_STAMP(2);
-    // the recurrent_fn outputs of the NEXT simulation of this lane are requested here, a whole
+    // the recurrent_fn outputs of the NEXT simulation of this lane are requested a whole
     // simulation before the update that consumes them, so that their latency is never waited for
-    {
+    auto prefetch = [&] {
       const int sn = sim + 1 < S ? sim + 1 : sim;
       const size_t e = (size_t)(active ? b : 0) * S + sn;
 AZ_UNROLL_A
@@ -186,7 +178,17 @@ AZ_UNROLL_K
         if (k < K) nx_value[k] = inj.value[e * K + k];
       nx_reward = inj.reward[e];
       nx_discount = inj.discount[e];
+    };
+    WavePath wp;
+    if (NOISY) {
+      wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
+                                           need_keys ? sim_keys : nullptr);
+      prefetch();
+    } else {
+      wp = az_wave_chase_lean(s, h, j, sim, d.max_depth, active, prefetch);
     }
+    if (j == 0) depth_sum += wp.dep;
+    AZ_TREE_STAMP(2);
     az_wave_update<AMAX, KMAX, NOISY, RULE == 1>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
                                       discount);
     AZ_TREE_STAMP(7);

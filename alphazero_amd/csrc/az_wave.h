@@ -403,7 +403,11 @@ AZ_DEV void az_wave_path_depth(const WaveLds& s, int h, int j, int t_exit, int m
 // ends on one scalar test per eight levels, a lane whose walk has ended keeps reading
 // selx[0] = 0 meanwhile, and levels past the depth cap (search.py:183) are walked too and
 // discarded by az_wave_path_depth.
-AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int max_depth, bool active) {
+// `between`: work of the caller that does not depend on the path (requesting the next evaluation),
+// placed between the issue of the path's read-back and its first use.
+template <typename Between>
+AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int max_depth, bool active,
+                                   Between&& between) {
   (void)sim;  // named by the stamp hook of diagnostic builds
   int t = 0;
   if (j == 0) {
@@ -425,8 +429,12 @@ AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int 
   WavePath w;
   w.e_prev = s.path[j > 0 ? j - 1 : 0];
   w.e_mine = s.path[j];
+  between();
   az_wave_path_depth(s, h, j, t, max_depth, active, w);
   return w;
+}
+AZ_DEV WavePath az_wave_chase_lean(const WaveLds& s, int h, int j, int sim, int max_depth, bool active) {
+  return az_wave_chase_lean(s, h, j, sim, max_depth, active, [] {});
 }
 
 // The same walk for the PUCT rules with per-visit noise: a cached pick that the noise could
@@ -574,12 +582,22 @@ AZ_UNROLL_A
   g.fsum1 = (float)(sum_visits + 1);
 AZ_UNROLL_A
   for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) g.ratio[a] = (float)vis[a] / g.fsum1;
+  g.scale = (d.maxvisit_init + (float)maxvisit) * d.value_scale;
+}
+
+// Pins the results of az_gumbel_pre where this is called: without it the compiler sinks the
+// whole computation to its uses behind the backup.
+template <int AMAX>
+AZ_DEV void az_gumbel_pre_pin(int A, GumbelPre<AMAX>& g) {
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
     if (a < A) {
-      g.ratio[a] = az_pin((float)vis[a] / g.fsum1);
-      g.probs[a] = az_pin(g.probs[a]);  // (computed here, not sunk to its use behind the backup)
+      g.ratio[a] = az_pin(g.ratio[a]);
+      g.probs[a] = az_pin(g.probs[a]);
     }
   g.sum_probs = az_pin(g.sum_probs);
-  g.scale = az_pin((d.maxvisit_init + (float)maxvisit) * d.value_scale);
+  g.scale = az_pin(g.scale);
 }
 
 // q: mean over atoms of reward + discount * child value per action; raw: mean raw value.
@@ -707,6 +725,7 @@ AZ_UNROLL_A
           if (!leaf && a == act) f.vis[a] = f.vis[a] + 1;
         }
       az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre);
+      az_gumbel_pre_pin<AMAX>(A, gpre);
     }
     // the edge from this position's node to the next node of the path
     const int jstart = dep - 1 - it * AZ_POS < AZ_POS - 1 ? dep - 1 - it * AZ_POS : AZ_POS - 1;
@@ -761,6 +780,16 @@ AZ_UNROLL_K
       }
     }
     AZ_WAVE_STAMP(5);
+    // The look-ahead words of the refreshed entry come from the selected child's entry: with few
+    // actions the entries of ALL children are requested here, before the rule runs, so that the
+    // read's latency is not added behind the rule.
+    constexpr bool kEarlyEntries = false;  // (measured: the extra reads cost more than the round trip they hide)
+    az_i32x4 child_entry[kEarlyEntries ? AMAX : 1];
+    if (kEarlyEntries) {
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < A) child_entry[a] = s.selx[mine ? f.cidx[a] + 1 : 0];
+    }
     int32_t sel_new = 0;
     const WaveLeaf wl = az_wave_leaf(s, dep > 0 ? dep : 1, sim);  // (an inactive lane reads level 0)
     if (mine) {
@@ -855,7 +884,18 @@ AZ_UNROLL_A
     az_i32x4 entry = {sel_new, 0, 0, 0};
     if (!NOISY) {
       const bool on_path = child_code != 0 && child_code == next_code;
-      const az_i32x4 stored = s.selx[child_code];
+      az_i32x4 stored;
+      if (kEarlyEntries) {
+        // (the edge to the evaluated node was unvisited when the entries were requested: its
+        // child is on the path, and the stored entry is not used then)
+        stored = az_i32x4{0, 0, 0, 0};
+        const int best_a = (sel_new >> 16) & 0xff;
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a == best_a) stored = child_entry[a];
+      } else {
+        stored = s.selx[child_code];
+      }
       const bool several = wp.dep_max >= AZ_POS;
       int32_t n0 = __builtin_amdgcn_update_dpp(0, entry.x, 0x130, 0xf, 0xf, false);
       if (several && top) n0 = carry_sel[0];
