@@ -171,13 +171,49 @@ AZ_DEV void az_env_step_t(EnvState& st, int action, EnvOut& o) {
     az_acrobot_step(st, action, o);
 }
 
+// Every branch steps into an EnvOut of its own and copies all of it out in one order: when the
+// branches end in stores to different elements of one array, the optimiser merges them into a
+// single store through a selected address, and the array then lives in scratch memory.
+AZ_DEV void az_env_out_copy(EnvOut& o, const EnvOut& t) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o.obs[i] = t.obs[i];
+  o.reward = t.reward;
+  o.terminated = t.terminated;
+  o.truncated = t.truncated;
+}
+
 AZ_DEV void az_env_step_rt(int env_id, EnvState& st, int action, EnvOut& o) {
-  if (env_id == AZ_ENV_CARTPOLE)
+  EnvOut t{};
+  if (env_id == AZ_ENV_CARTPOLE) {
+    az_cartpole_step(st, action, t);
+    az_env_out_copy(o, t);
+  } else if (env_id == AZ_ENV_MOUNTAINCAR) {
+    az_mountaincar_step(st, action, t);
+    az_env_out_copy(o, t);
+  } else {
+    az_acrobot_step(st, action, t);
+    az_env_out_copy(o, t);
+  }
+}
+
+// The environments an action count admits (az_env_num_actions): with A known at compile time
+// the other environments' code is not generated.
+template <int A_EXACT>
+AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut& o) {
+  if (A_EXACT == 2) {
     az_cartpole_step(st, action, o);
-  else if (env_id == AZ_ENV_MOUNTAINCAR)
-    az_mountaincar_step(st, action, o);
-  else
-    az_acrobot_step(st, action, o);
+  } else if (A_EXACT == 3) {
+    EnvOut t{};
+    if (env_id == AZ_ENV_MOUNTAINCAR) {
+      az_mountaincar_step(st, action, t);
+      az_env_out_copy(o, t);
+    } else {
+      az_acrobot_step(st, action, t);
+      az_env_out_copy(o, t);
+    }
+  } else {
+    az_env_step_rt(env_id, st, action, o);
+  }
 }
 
 AZ_DEV void az_env_obs(int env_id, const EnvState& st, float* obs) {

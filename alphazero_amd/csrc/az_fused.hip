@@ -123,6 +123,10 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
 
 // running_statistics.py:183-199 on one observation row, written in the permuted
 // activation layout of the first dense layer (both networks read the same rows).
+// IN_REGISTERS: `obs` is an EnvOut's array of 6 (only ever indexed with constants, so that it
+// stays in registers; entries past obs_dim are computed on and dropped); otherwise `obs` points
+// at obs_dim floats in memory.
+template <bool IN_REGISTERS>
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
   // all reads first, then the divisions side by side, then the writes: one LDS round trip and
   // one division's latency instead of one of each per element (obs_dim <= 6, EnvOut)
@@ -130,12 +134,11 @@ AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const flo
   float mean[6], dev[6], x[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int ii = i < md.obs_dim ? i : 0;
-    mean[i] = s.norm_mean[ii];
-    dev[i] = s.norm_std[ii];
+    mean[i] = s.norm_mean[i];  // (the normaliser's LDS rows are longer than 6)
+    dev[i] = s.norm_std[i];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = (obs[i < md.obs_dim ? i : 0] - mean[i]) / dev[i];
+  for (int i = 0; i < 6; ++i) x[i] = ((IN_REGISTERS ? obs[i] : obs[i < md.obs_dim ? i : 0]) - mean[i]) / dev[i];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
     if (i < md.obs_dim) s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = x[i];
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
-  if (tid < 16 && b < B) az_store_obs(md, s, tid, obs + (size_t)b * md.obs_dim);
+  if (tid < 16 && b < B) az_store_obs<false>(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
   MlpRegs regs;
   az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
@@ -193,9 +196,11 @@ extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float*
 }
 
 // alphazero.py:317-339 on one lane: environment step, reward and discount.
+// A_EXACT: the model's action count when it is known at compile time, else 0.
+template <int A_EXACT = 0>
 AZ_DEV void az_model_env_step(const ModelDev& md, EnvState& st, int action, EnvOut& o, float& reward,
                               float& discount) {
-  az_env_step_rt(md.env_id, st, action, o);
+  az_env_step_for_actions<A_EXACT>(md.env_id, st, action, o);
   reward = o.reward;
   discount = md.gamma * (o.truncated != 0.0f ? 1.0f : 1.0f - o.terminated);
 }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) {
     EnvState st;
-    EnvOut o;
+    EnvOut o{};
     for (int i = 0; i < 4; ++i) st.s[i] = state[(size_t)b * 4 + i];
     st.time = time[b];
     float r, dsc;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
     time[b] = st.time;
     reward[b] = r;
     discount[b] = dsc;
-    az_store_obs(md, s, tid, o.obs);
+    az_store_obs<true>(md, s, tid, o.obs);
   }
   __syncthreads();
   MlpRegs regs;
@@ -290,9 +295,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
 #pragma unroll
       for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)parent * 4 + i];
       st.time = l.et[parent];
-      EnvOut o;
+      EnvOut o{};
       az_model_env_step(md, st, action, o, reward, discount);
-      az_store_obs(md, s, tid, o.obs);
+      az_store_obs<true>(md, s, tid, o.obs);
     }
     __syncthreads();
     az_forward_tile<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
@@ -314,7 +319,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
 __device__ long long az_sim_stamps[64][16];
 #define AZ_SIM_STAMP(k)                                                                        \
   do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
     if (blockIdx.x == 0 && tid == 0 && sim < 64) az_sim_stamps[sim][k] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
 #else
 #define AZ_SIM_STAMP(k) \
@@ -401,10 +408,10 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
           for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)wl.parent * 4 + i];
           st.time = l.et[wl.parent];
         }
-        EnvOut o;
+        EnvOut o{};
         float reward, discount;
         AZ_SIM_STAMP(6);
-        az_model_env_step(md, st, wl.action, o, reward, discount);
+        az_model_env_step<EXACT ? AMAX : 0>(md, st, wl.action, o, reward, discount);
         AZ_SIM_STAMP(7);
         if (emb) {
 #pragma unroll
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         l.et[wl.node] = st.time;
         ws.hdr[4] = (int32_t)az_f2u(reward);
         ws.hdr[5] = (int32_t)az_f2u(discount);
-        az_store_obs(md, s, ln, o.obs);
+        az_store_obs<true>(md, s, ln, o.obs);
         AZ_SIM_STAMP(8);
       }
       // The path is known now, and the rows the update will need depend on the path only: when a
