@@ -363,7 +363,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
   uint32_t* sim_keys = reinterpret_cast<uint32_t*>(tree_lds + AZ_WG_LANES * WaveLds::lane_words(S));
-  float* emb = emb_in_lds ? reinterpret_cast<float*>(sim_keys + 2 * S) + ln * (S + 1) * 5 : nullptr;
+  float* const emb_base = reinterpret_cast<float*>(sim_keys + 2 * S);
+  float* emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
   az_stage_inputs(md, s, tid, blockDim.x);
@@ -399,6 +400,11 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         depth_sum += wp.dep;
         const WaveLeaf wl = az_wave_leaf(ws, wp.dep, sim);
         EnvState st;
+        // Addresses that depend on the thread only are derived again in every simulation
+        // (from a value the optimiser cannot see through): hoisted out of the loop they
+        // would sit in registers across the networks, where there are none to spare.
+        const int ln_now = az_opaque(ln);
+        float* const emb = emb_in_lds ? emb_base + ln_now * (S + 1) * 5 : nullptr;
         if (emb) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) st.s[i] = emb[wl.parent * 5 + i];
@@ -418,13 +424,14 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
           for (int i = 0; i < 4; ++i) emb[wl.node * 5 + i] = st.s[i];
           emb[wl.node * 5 + 4] = az_u2f((uint32_t)st.time);
         }
-        // the caller's copy of the new node's environment state
+        ws.hdr[4] = (int32_t)az_f2u(reward);
+        ws.hdr[5] = (int32_t)az_f2u(discount);
+        az_store_obs<true>(md, s, ln_now, o.obs);
+        // the caller's copy of the new node's environment state (last: nothing above then has
+        // to wait behind these stores in the vector-memory counter)
 #pragma unroll
         for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
         l.et[wl.node] = st.time;
-        ws.hdr[4] = (int32_t)az_f2u(reward);
-        ws.hdr[5] = (int32_t)az_f2u(discount);
-        az_store_obs<true>(md, s, ln, o.obs);
         AZ_SIM_STAMP(8);
       }
       // The path is known now, and the rows the update will need depend on the path only: when a

@@ -529,6 +529,31 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az
   AZ_STAMP_AT();
   if (rider) az_mlp_tile_epilogue(u.o2, 0, acc2, bias2, lds_base, lane);
   if (!last) return;
+  if (u.o0.act) {
+    // Both tiles' activations in one basic block: four independent chains of packed
+    // instructions, interleaved (az_swish2x4), where one tile after the other runs at the
+    // latency of a single chain.  (A single-tile unit has acc1 == acc0; its second
+    // tile is computed and dropped.)
+    const MlpTile& o = u.o0;
+    az_f32x2 v[4] = {az_f32x2{acc0.x, acc0.y} + az_splat2(bias0), az_f32x2{acc0.z, acc0.w} + az_splat2(bias0),
+                     az_f32x2{acc1.x, acc1.y} + az_splat2(bias1), az_f32x2{acc1.z, acc1.w} + az_splat2(bias1)};
+    az_swish2x4(v);
+    const az_f32x2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    float* out = lds_base + o.out_off + (lane >> 4) * 4 * o.out_stride;
+    float* q = out + az_act_index(o.n0 + (lane & 15), o.out_np);
+    q[0] = v0.x;
+    q[o.out_stride] = v0.y;
+    q[2 * o.out_stride] = v1.x;
+    q[3 * o.out_stride] = v1.y;
+    if (two) {
+      float* q1 = out + az_act_index(o.n0 + 16 + (lane & 15), o.out_np);
+      q1[0] = v2.x;
+      q1[o.out_stride] = v2.y;
+      q1[2 * o.out_stride] = v3.x;
+      q1[3 * o.out_stride] = v3.y;
+    }
+    return;
+  }
   az_mlp_tile_epilogue(u.o0, 0, acc0, bias0, lds_base, lane);
   if (two) az_mlp_tile_epilogue(u.o0, 16, acc1, bias1, lds_base, lane);
 }

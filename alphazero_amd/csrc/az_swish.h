@@ -61,4 +61,45 @@ AZ_DEV az_f32x2 az_rcp2_exact(az_f32x2 d) {
 
 AZ_DEV az_f32x2 az_swish2(az_f32x2 x) { return x * az_rcp2_exact(az_one_plus_exp_neg2(x)); }
 
+// az_swish2 on four pairs at once, step by step across the four: every instruction has three
+// independent ones between itself and its consumer, so the sequence runs at the issue rate
+// instead of at the latency of one dependent chain.  The empty asm after each step keeps
+// the order (left alone, the scheduler -- short of registers next to the weight slots --
+// runs the chains nearly one after the other).  Same operations per element as az_swish2.
+#define AZ_SW4(arr, expr)                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) arr[i] = (expr); \
+  asm volatile("" : "+v"(arr[0]), "+v"(arr[1]), "+v"(arr[2]), "+v"(arr[3]))
+AZ_DEV void az_swish2x4(az_f32x2 (&x)[4]) {
+  const az_f32x2 one = az_splat2(1.0f);
+  az_f32x2 t[4], m[4], kf[4], r[4], rr[4], p[4], sc[4], d[4], y[4], e[4], q[4];
+  // 1 + exp(t), as in az_one_plus_exp_neg2
+  AZ_SW4(t, (az_f32x2{__builtin_amdgcn_fmed3f(-x[i].x, -64.0f, 64.0f), __builtin_amdgcn_fmed3f(-x[i].y, -64.0f, 64.0f)}));
+  AZ_SW4(m, t[i] * az_splat2(1.44269502162933349609375f));
+  AZ_SW4(m, m[i] + az_splat2(12582912.0f));
+  AZ_SW4(kf, m[i] - az_splat2(12582912.0f));
+  AZ_SW4(r, az_fma2(kf[i], az_splat2(-0.693359375f), t[i]));
+  AZ_SW4(r, az_fma2(kf[i], az_splat2(2.12194440e-4f), r[i]));
+  AZ_SW4(p, az_fma2(az_splat2(1.9875691500e-4f), r[i], az_splat2(1.3981999507e-3f)));
+  AZ_SW4(p, az_fma2(p[i], r[i], az_splat2(8.3334519073e-3f)));
+  AZ_SW4(p, az_fma2(p[i], r[i], az_splat2(4.1665795894e-2f)));
+  AZ_SW4(p, az_fma2(p[i], r[i], az_splat2(1.6666665459e-1f)));
+  AZ_SW4(p, az_fma2(p[i], r[i], az_splat2(5.0000001201e-1f)));
+  AZ_SW4(rr, r[i] * r[i]);
+  AZ_SW4(p, az_fma2(p[i], rr[i], r[i]));
+  AZ_SW4(p, p[i] + one);
+  AZ_SW4(sc, (az_f32x2{az_u2f((az_f2u(m[i].x) << 23) + 0x3f800000u), az_u2f((az_f2u(m[i].y) << 23) + 0x3f800000u)}));
+  AZ_SW4(p, p[i] * sc[i]);
+  AZ_SW4(d, one + p[i]);
+  // 1 / d, as in az_rcp2_exact
+  AZ_SW4(y, (az_f32x2{__builtin_amdgcn_rcpf(d[i].x), __builtin_amdgcn_rcpf(d[i].y)}));
+  AZ_SW4(e, az_fma2(-d[i], y[i], one));
+  AZ_SW4(y, az_fma2(e[i], y[i], y[i]));
+  AZ_SW4(e, az_fma2(-d[i], y[i], one));
+  AZ_SW4(q, az_fma2(e[i], y[i], y[i]));
+  AZ_SW4(e, az_fma2(-d[i], q[i], one));
+  AZ_SW4(q, az_fma2(e[i], y[i], q[i]));
+  AZ_SW4(x, x[i] * q[i]);
+}
+#undef AZ_SW4
+
 #endif  // AZ_SWISH_H_
