@@ -126,22 +126,28 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
 // IN_REGISTERS: `obs` is an EnvOut's array of 6 (only ever indexed with constants, so that it
 // stays in registers; entries past obs_dim are computed on and dropped); otherwise `obs` points
 // at obs_dim floats in memory.
-template <bool IN_REGISTERS>
+// OBS_DIM: the observation size when it is known at compile time, else 0 (md.obs_dim).
+template <bool IN_REGISTERS, int OBS_DIM = 0>
 AZ_DEV void az_store_obs(const ModelDev& md, const MlpLds& s, int row, const float* obs) {
   // all reads first, then the divisions side by side, then the writes: one LDS round trip and
   // one division's latency instead of one of each per element (obs_dim <= 6, EnvOut)
   const int kp = md.val.kp[0];
-  float mean[6], dev[6], x[6];
+  const int n = OBS_DIM ? OBS_DIM : md.obs_dim;
+  constexpr int N = OBS_DIM ? OBS_DIM : 6;
+  float mean[N], dev[N], x[N];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < N; ++i) {
     mean[i] = s.norm_mean[i];  // (the normaliser's LDS rows are longer than 6)
     dev[i] = s.norm_std[i];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = ((IN_REGISTERS ? obs[i] : obs[i < md.obs_dim ? i : 0]) - mean[i]) / dev[i];
+  for (int i = 0; i < N; ++i) x[i] = ((IN_REGISTERS ? obs[i] : obs[i < n ? i : 0]) - mean[i]) / dev[i];
+  // (pinned: the quotients are all computed here, not one by one under the conditions below)
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-    if (i < md.obs_dim) s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = x[i];
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) s.in0[row * AZ_IN0_STRIDE + az_act_index(i, kp)] = x[i];
 }
 
 // Kernel prologue: zeroes the first layer's input rows and copies the normaliser into
@@ -373,10 +379,19 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
     if (active) {
       Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
       az_wave_init<AMAX, KMAX, NOISY>(c, l, ws, b);
-      if (emb) {
-        for (int i = 0; i < 4; ++i) emb[i] = l.es[i];
-        emb[4] = az_u2f((uint32_t)l.et[0]);
-      }
+    }
+  }
+  if (emb && active) {
+    // all of the caller's states, not only the root's: slots that no simulation expands (a
+    // depth limit can leave some) are written back unchanged after the last simulation
+    Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
+    for (int node = j; node <= S; node += AZ_POS) {
+      const az_f32x4 st4 = *reinterpret_cast<const az_f32x4*>(l.es + (size_t)node * 4);
+      emb[node * 5] = st4.x;
+      emb[node * 5 + 1] = st4.y;
+      emb[node * 5 + 2] = st4.z;
+      emb[node * 5 + 3] = st4.w;
+      emb[node * 5 + 4] = az_u2f((uint32_t)l.et[node]);
     }
   }
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
@@ -426,12 +441,14 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         }
         ws.hdr[4] = (int32_t)az_f2u(reward);
         ws.hdr[5] = (int32_t)az_f2u(discount);
-        az_store_obs<true>(md, s, ln_now, o.obs);
-        // the caller's copy of the new node's environment state (last: nothing above then has
-        // to wait behind these stores in the vector-memory counter)
+        az_store_obs<true, (EXACT && AMAX == 2) ? 4 : 0>(md, s, ln_now, o.obs);  // two actions: CartPole
+        // the caller's copy of the new node's environment state (with the states in LDS it is
+        // written once, after the last simulation)
+        if (!emb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
-        l.et[wl.node] = st.time;
+          for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
+          l.et[wl.node] = st.time;
+        }
         AZ_SIM_STAMP(8);
       }
       // The path is known now, and the rows the update will need depend on the path only: when a
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       // The first unit's weights are requested before the barrier, so that they arrive while
       // the slower waves still walk their trees.  The weight registers are not kept across
       // the update below, which needs them.
-      az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
+      az_forward_prime<AZ_MLP_WAVES>(md, s, wave, az_opaque(lane), regs);  // (see ln_now)
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
@@ -456,6 +473,17 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
                                         s.value + ln * AZ_MAX_ATOMS, reward, discount,
                                         kPrefetch ? &P0 : nullptr);
       AZ_SIM_STAMP(5);
+    }
+  }
+  if (emb_in_lds && active) {
+    // (a simulation that ends on the depth limit steps an existing node's state into the slot
+    // it already has -- az_wave_leaf -- so the LDS copy is the final one either way)
+    Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
+    const float* e = emb_base + ln * (S + 1) * 5;
+    for (int node = 1 + j; node <= S; node += AZ_POS) {
+      az_f32x4 st4 = {e[node * 5], e[node * 5 + 1], e[node * 5 + 2], e[node * 5 + 3]};
+      *reinterpret_cast<az_f32x4*>(l.es + (size_t)node * 4) = st4;
+      l.et[node] = (int32_t)az_f2u(e[node * 5 + 4]);
     }
   }
   az_add_depth(sum_depth, (long long)depth_sum);
