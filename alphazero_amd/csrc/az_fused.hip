@@ -404,22 +404,38 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
     WaveRow<AMAX, KMAX> P0;
     WavePath wp;
     {
-      Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
+      // Everything that depends on the thread only is derived again here, and once more
+      // before the update, from a value the optimiser cannot see through: hoisted out of
+      // the loop, those indices and addresses would sit in registers across the networks,
+      // where there are none to spare (a spilled one costs a reload and, worse, a wait for
+      // every vector-memory operation in flight).
+      const int tid = az_opaque((int)threadIdx.x), lane = tid & 63;
+      const int ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
+      const int b = blockIdx.x * AZ_WG_LANES + ln;
+      const bool active = b < d.B, leader = active && j == 0;
+      const WaveLds ws(tree_lds, ln, S);
+      // The first unit's weights are requested first of all: the eight waves' requests
+      // (288 KB) keep the CU's memory pipeline busy for about as long as the walk, the
+      // environment step and the observation take, and none of those needs many registers
+      // or waits for vector memory.  The weight registers are not kept across the update at
+      // the end of the loop body, which needs them.
+      // (in three portions, so that no wave sits in the queue behind 36 loads of each of
+      // the other seven before it can start its walk)
+      const MlpPre first_unit = az_forward_prime_begin<AZ_MLP_WAVES>(s, wave, lane);
+      az_forward_prime_slots<0, 6>(first_unit, lane, regs);
+      Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
       if (NOISY)
         wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
                                              need_keys ? sim_keys : nullptr);
       else
         wp = az_wave_chase_lean(ws, h, j, sim, d.max_depth, active);
       AZ_SIM_STAMP(1);
+      az_forward_prime_slots<6, 11>(first_unit, lane, regs);
       if (leader) {
         depth_sum += wp.dep;
         const WaveLeaf wl = az_wave_leaf(ws, wp.dep, sim);
         EnvState st;
-        // Addresses that depend on the thread only are derived again in every simulation
-        // (from a value the optimiser cannot see through): hoisted out of the loop they
-        // would sit in registers across the networks, where there are none to spare.
-        const int ln_now = az_opaque(ln);
-        float* const emb = emb_in_lds ? emb_base + ln_now * (S + 1) * 5 : nullptr;
+        float* const emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
         if (emb) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) st.s[i] = emb[wl.parent * 5 + i];
@@ -428,6 +444,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
 #pragma unroll
           for (int i = 0; i < 4; ++i) st.s[i] = l.es[(size_t)wl.parent * 4 + i];
           st.time = l.et[wl.parent];
+          // waited for in here: left to the compiler, the wait lands behind the join, where it
+          // also holds up the other branch until the weights above have arrived
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         }
         EnvOut o{};
         float reward, discount;
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         }
         ws.hdr[4] = (int32_t)az_f2u(reward);
         ws.hdr[5] = (int32_t)az_f2u(discount);
-        az_store_obs<true, (EXACT && AMAX == 2) ? 4 : 0>(md, s, ln_now, o.obs);  // two actions: CartPole
+        az_store_obs<true, (EXACT && AMAX == 2) ? 4 : 0>(md, s, ln, o.obs);  // two actions: CartPole
         // the caller's copy of the new node's environment state (with the states in LDS it is
         // written once, after the last simulation)
         if (!emb) {
@@ -451,23 +470,30 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         }
         AZ_SIM_STAMP(8);
       }
+      az_forward_prime_slots<11, AZ_SLOTS>(first_unit, lane, regs);
       // The path is known now, and the rows the update will need depend on the path only: when a
       // row fits in a few registers its loads are issued before the networks run, so that
       // their latency hides behind the MLPs.
       if (kPrefetch) az_wave_load<AMAX, KMAX>(l, active, j, wp.dep, sim, wp.e_prev, wp.e_mine, P0);
       AZ_SIM_STAMP(9);
-      // The first unit's weights are requested before the barrier, so that they arrive while
-      // the slower waves still walk their trees.  The weight registers are not kept across
-      // the update below, which needs them.
-      az_forward_prime<AZ_MLP_WAVES>(md, s, wave, az_opaque(lane), regs);  // (see ln_now)
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
+      az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+      // Nothing is in flight any more (the row prefetch returned long ago), and saying so
+      // here costs nothing.  Left unsaid, the compiler has to assume on some paths that the
+      // prefetch is still pending when its registers are reused in the next simulation, and
+      // waits there -- behind that simulation's 36 weight loads.
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     }
-    az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
     AZ_SIM_STAMP(4);
     {
-      Lane<AMAX, KMAX> l(t, active ? az_opaque(b) : 0, S + 1, A, K);
+      const int tid = az_opaque((int)threadIdx.x);
+      const int ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
+      const int b = blockIdx.x * AZ_WG_LANES + ln;
+      const bool active = b < d.B;
+      const WaveLds ws(tree_lds, ln, S);
+      Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
       const float reward = az_u2f((uint32_t)ws.hdr[4]), discount = az_u2f((uint32_t)ws.hdr[5]);
       az_wave_update<AMAX, KMAX, NOISY, RULE == 1>(c, l, ws, active, h, j, sim, wp, s.logits + ln * AZ_MAX_ACTIONS,
                                         s.value + ln * AZ_MAX_ATOMS, reward, discount,

@@ -559,18 +559,25 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az
 }
 
 // Loads the weights of the wave's first unit; call before az_forward_tile (once, when
-// the calls wrap).
+// the calls wrap).  In two steps for callers that spread the 36 loads over other work:
+// az_forward_prime_begin fetches the refill fields, az_forward_prime_slots issues the loads of
+// the slots [KB0, KB1) -- every slot exactly once, in ascending order.
 template <int NWAVES>
-AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
-  const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
-  if (n_tab <= 0) return;
+AZ_DEV MlpPre az_forward_prime_begin(const MlpLds& s, int wave, int lane) {
   MlpUnit unused;
   MlpPre cur;
   az_mlp_table_decode(az_mlp_table_read(s, wave, 0, 0, lane), unused, cur);
+  cur.nkb = __builtin_amdgcn_readfirstlane(s.tab_n[wave]) > 0 ? cur.nkb : 0;  // 0: no unit, no loads
+  return cur;
+}
+
+template <int KB0, int KB1>
+AZ_DEV void az_forward_prime_slots(const MlpPre& cur, int lane, MlpRegs& R) {
+  if (cur.nkb <= 0) return;
   // same order and count as a unit's refills
-  const int nk = cur.nkb > 0 ? cur.nkb - 1 : 0, nk2 = cur.nkb2 > 0 ? cur.nkb2 - 1 : 0;
+  const int nk = cur.nkb - 1, nk2 = cur.nkb2 > 0 ? cur.nkb2 - 1 : 0;
 #pragma unroll
-  for (int kb = 0; kb < AZ_SLOTS; ++kb) {
+  for (int kb = KB0; kb < KB1; ++kb) {
     const int kc = kb < nk ? kb : nk;
     R.W0[kb] = az_ldg4(cur.w0 + (size_t)kc * 64 + lane);
     R.W1[kb] = az_ldg4(cur.w1 + (size_t)kc * 64 + lane);
@@ -579,6 +586,12 @@ AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int 
       R.W2[kb < AZ_RIDER_SLOTS ? kb : 0] = az_ldg4(cur.w2 + (size_t)kc2 * 64 + lane);
     }
   }
+}
+
+template <int NWAVES>
+AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
+  const MlpPre cur = az_forward_prime_begin<NWAVES>(s, wave, lane);
+  az_forward_prime_slots<0, AZ_SLOTS>(cur, lane, R);
 }
 
 // Both networks on the 16 rows staged in s.in0 -> s.logits / s.value.  Called by all
