@@ -395,8 +395,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
     }
   }
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  if (j == 0) ws.hdr[6] = 0;  // the lane's sum of path depths (in LDS: one register fewer across the networks)
   __syncthreads();
-  int depth_sum = 0;
   for (int sim = 0; sim < S; ++sim) {
     AZ_SIM_STAMP(0);
     MlpRegs regs;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       AZ_SIM_STAMP(1);
       az_forward_prime_slots<6, 11>(first_unit, lane, regs);
       if (leader) {
-        depth_sum += wp.dep;
+        __hip_atomic_fetch_add(&ws.hdr[6], wp.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // (one LDS add, nothing returned)
         const WaveLeaf wl = az_wave_leaf(ws, wp.dep, sim);
         EnvState st;
         float* const emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
@@ -501,18 +501,26 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       AZ_SIM_STAMP(5);
     }
   }
-  if (emb_in_lds && active) {
-    // (a simulation that ends on the depth limit steps an existing node's state into the slot
-    // it already has -- az_wave_leaf -- so the LDS copy is the final one either way)
-    Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
-    const float* e = emb_base + ln * (S + 1) * 5;
-    for (int node = 1 + j; node <= S; node += AZ_POS) {
-      az_f32x4 st4 = {e[node * 5], e[node * 5 + 1], e[node * 5 + 2], e[node * 5 + 3]};
-      *reinterpret_cast<az_f32x4*>(l.es + (size_t)node * 4) = st4;
-      l.et[node] = (int32_t)az_f2u(e[node * 5 + 4]);
+  {
+    // (thread indices derived afresh, as in the loop: nothing of the prologue stays live)
+    const int tid = az_opaque((int)threadIdx.x);
+    const int ln = tid / AZ_POS, j = tid & (AZ_POS - 1);
+    const int b = blockIdx.x * AZ_WG_LANES + ln;
+    const bool active = b < d.B;
+    if (emb_in_lds && active) {
+      // (a simulation that ends on the depth limit steps an existing node's state into the
+      // slot it already has -- az_wave_leaf -- so the LDS copy is the final one either way)
+      Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
+      const float* e = emb_base + ln * (S + 1) * 5;
+      for (int node = 1 + j; node <= S; node += AZ_POS) {
+        az_f32x4 st4 = {e[node * 5], e[node * 5 + 1], e[node * 5 + 2], e[node * 5 + 3]};
+        *reinterpret_cast<az_f32x4*>(l.es + (size_t)node * 4) = st4;
+        l.et[node] = (int32_t)az_f2u(e[node * 5 + 4]);
+      }
     }
+    const WaveLds ws(tree_lds, ln, S);
+    az_add_depth(sum_depth, (long long)(active && j == 0 ? ws.hdr[6] : 0));
   }
-  az_add_depth(sum_depth, (long long)depth_sum);
 }
 
 extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
