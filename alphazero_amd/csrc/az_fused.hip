@@ -369,17 +369,15 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
   uint32_t* sim_keys = reinterpret_cast<uint32_t*>(tree_lds + AZ_WG_LANES * WaveLds::lane_words(S));
-  float* const emb_base = reinterpret_cast<float*>(sim_keys + 2 * S);
+  float* const emb_base = reinterpret_cast<float*>(sim_keys + az_key_words(S));
   float* emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
   az_stage_inputs(md, s, tid, blockDim.x);
-  if (j == 0) {
-    ws.selx[0] = az_i32x4{0, 0, 0, 0};
-    if (active) {
-      Lane<AMAX, KMAX> l(t, b, S + 1, A, K);
-      az_wave_init<AMAX, KMAX, NOISY>(c, l, ws, b);
-    }
+  if (j == 0) ws.selx[0] = az_i32x4{0, 0, 0, 0};
+  {
+    Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
+    az_wave_init<AMAX, KMAX, NOISY>(c, l, ws, b, j, active);
   }
   if (emb && active) {
     // all of the caller's states, not only the root's: slots that no simulation expands (a
@@ -538,7 +536,7 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp) * 4;
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, lds, false)) {
-    size_t lds2 = lds + ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)2 * d->S) * 4;
+    size_t lds2 = lds + ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)az_key_words(d->S)) * 4;
     const size_t emb_bytes = (size_t)AZ_WG_LANES * (d->S + 1) * 5 * 4;
     const int emb_in_lds = lds2 + emb_bytes <= 160 * 1024;
     if (emb_in_lds) lds2 += emb_bytes;

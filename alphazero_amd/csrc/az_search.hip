@@ -108,12 +108,26 @@ AZ_UNROLL_K
 
 #ifdef AZ_STAMP
 #define AZ_TREE_STAMP(k) AZ_WAVE_STAMP(k)
+// kernel entry, simulation loop entered, loop left, kernel end (thread 0 of workgroup 0)
+__device__ long long az_tree_edges[4];
+#define AZ_TREE_EDGE(k)                                                                     \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0) az_tree_edges[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 extern "C" int az_debug_read_tree_stamps(long long* host_out) {
   AZ_HIP(hipDeviceSynchronize());
   AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_tree_stamps), sizeof(long long) * 64 * 8));
   return AZ_OK;
 }
+extern "C" int az_debug_read_tree_edges(long long* host_out) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_tree_edges), sizeof(long long) * 4));
+  return AZ_OK;
+}
 #else
+#define AZ_TREE_EDGE(k) \
+  do {                  \
+  } while (0)
 #define AZ_TREE_STAMP(k) \
   do {                   \
   } while (0)
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_injected(
     SearchCtx c_in, az_tree t, az_injected inj, unsigned long long* sum_depth) {
   constexpr int tree_in_lds = TREE_LDS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  AZ_TREE_EDGE(0);
   const SearchCtx c = az_rule_ctx<RULE>(c_in);
   const az_search_desc& d = c.d;
   const int A = EXACT ? AMAX : d.A, K = EXACT ? KMAX : d.K, S = d.S;
@@ -139,19 +154,9 @@ __global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_injected(
   WaveLds s(lds, ln, S);
   uint32_t* sim_keys = reinterpret_cast<uint32_t*>(lds + AZ_WG_LANES * WaveLds::lane_words(S));
   const int lanes_here = d.B - b0 < AZ_WG_LANES ? d.B - b0 : AZ_WG_LANES;
-  TreeLds tl(reinterpret_cast<float*>(sim_keys + 2 * S), S + 1, A, K);
-  if (tree_in_lds) tl.copy(t, b0, lanes_here, true, tid, blockDim.x);
-  const az_tree tv = tree_in_lds ? tl.view() : t;
-  Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
-  const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
-  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
-  if (j == 0) s.selx[0] = az_i32x4{0, 0, 0, 0};
-  __syncthreads();
-  if (j == 0 && active) az_wave_init<AMAX, KMAX, NOISY>(c, l, s, b);
-  __syncthreads();
-  long long depth_sum = 0;
+  TreeLds tl(reinterpret_cast<float*>(sim_keys + az_key_words(S)), S + 1, A, K);
+  // the first simulation's recurrent_fn outputs are requested before anything waits for memory
   float ev_logits[AMAX], ev_value[KMAX], reward, discount;
-  float nx_logits[AMAX], nx_value[KMAX], nx_reward, nx_discount;
   {
     const size_t e = (size_t)(active ? b : 0) * S;
 AZ_UNROLL_A
@@ -163,6 +168,18 @@ AZ_UNROLL_K
     reward = inj.reward[e];
     discount = inj.discount[e];
   }
+  if (tree_in_lds) tl.template copy<true>(t, b0, lanes_here, tid, blockDim.x);
+  const az_tree tv = tree_in_lds ? tl.view() : t;
+  Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
+  const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
+  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
+  if (j == 0) s.selx[0] = az_i32x4{0, 0, 0, 0};
+  __syncthreads();
+  az_wave_init<AMAX, KMAX, NOISY>(c, l, s, b, j, active);
+  __syncthreads();
+  long long depth_sum = 0;
+  float nx_logits[AMAX], nx_value[KMAX], nx_reward, nx_discount;
+  AZ_TREE_EDGE(1);
   for (int sim = 0; sim < S; ++sim) {
     AZ_TREE_STAMP(0);
     // the recurrent_fn outputs of the NEXT simulation of this lane are requested a whole
@@ -199,16 +216,18 @@ AZ_UNROLL_K
     reward = nx_reward;
     discount = nx_discount;
   }
+  AZ_TREE_EDGE(2);
   if (tree_in_lds) {
     __syncthreads();
-    tl.copy(t, b0, lanes_here, false, tid, blockDim.x);
+    tl.template copy<false>(t, b0, lanes_here, tid, blockDim.x);
   }
   az_add_depth(sum_depth, depth_sum);
+  AZ_TREE_EDGE(3);
 }
 
 // LDS bytes of the cooperative form's own state (cached selections, path, root inputs, keys).
 static size_t az_wave_lds_bytes(const az_search_desc* d) {
-  return ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)2 * d->S) * 4;
+  return ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)az_key_words(d->S)) * 4;
 }
 
 // Whether the cooperative form applies (see az_wave.h) and fits in LDS next to

@@ -27,3 +27,7 @@ for sim in range(min(S, 64)):
     nxt = buf[sim + 1][0] if sim + 1 < min(S, 64) else r[7]
     d = [int(r[i + 1] - r[i]) for i in range(7)] + [int(nxt - r[7])]
     print(f"{sim:3d} {int(nxt - r[0]):7d} | " + " ".join(f"{x:9d}" for x in d))
+edges = np.zeros(4, np.int64)
+lib.az_debug_read_tree_edges.argtypes = [C.c_void_p]
+lib.az_debug_read_tree_edges(edges.ctypes.data_as(C.c_void_p))
+print("kernel: prologue %d, simulations %d, epilogue %d cycles" % tuple(int(edges[i + 1] - edges[i]) for i in range(3)))
