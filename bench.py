@@ -81,9 +81,9 @@ def make_networks(env_id, seed, device):
 class Actor:
     """alphazero.py:287-403 actor_step with the search on the fused HIP path."""
 
-    def __init__(self, env_id, B, S, device, seed=0):
+    def __init__(self, env_id, B, S, device, seed=0, variant="gumbel"):
         import alphazero_amd as mctx
-        self.mctx, self.B, self.S = mctx, B, S
+        self.mctx, self.B, self.S, self.variant = mctx, B, S, variant
         self.env = mctx.envs.make(env_id, episode_length=500)
         self.pol, self.val = make_networks(env_id, 1, device)
         self.model = mctx.FusedModel(env_id, self.pol, self.val, gamma=0.99)
@@ -98,13 +98,37 @@ class Actor:
         self.key, search_key = prng.split(self.key, 2)
         logits, value = self.model.forward(self.state.obs)
         root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=self.state.embedding)
-        out = mctx.gumbel_muzero_policy((), search_key, root, self.recurrent_fn, self.S,
-                                        max_num_considered_actions=16, qtransform=self.qtransform,
-                                        stats=stats)
+        if self.variant == "sampled":  # the reference trainer's default (alphazero.py:312-326)
+            out = mctx.sampled_muzero_policy((), search_key, root, self.recurrent_fn, self.S,
+                                             num_samples=100, stats=stats)
+        else:
+            out = mctx.gumbel_muzero_policy((), search_key, root, self.recurrent_fn, self.S,
+                                            max_num_considered_actions=16, qtransform=self.qtransform,
+                                            stats=stats)
         action, search_value, log_prob = mctx.actor_post(out.search_tree, out.action_weights,
                                                          out.action, logits, deterministic=False)
         self.env.step_(self.state, action)
         return out
+
+
+def secondary_sampled(args, B, S, device, steps=5):
+    """The same actor step with the reference trainer's default policy, sampled_muzero_policy with
+    100 samples (PUCT with Dirichlet noise at the root and tie-break noise in the tree)."""
+    actor = Actor(args.env, B, S, device, seed=7, variant="sampled")
+    for _ in range(2):
+        actor.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ktimes = []
+    for _ in range(steps):
+        stats = {"record_events": True}
+        actor.step(stats)
+        ktimes.append(stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = float(np.mean([s["events"][0][0].elapsed_time(s["events"][0][1]) for s in ktimes]))
+    return {"value": round(B * S * steps / dt, 1), "unit": "simulations/s", "num_samples": 100,
+            "ms_per_step": round(dt / steps * 1e3, 4), "search_kernel_ms_per_launch": round(kt, 4)}
 
 
 def pmc_traffic(kernel):
@@ -285,6 +309,7 @@ def main():
         }
         if world == 1:
             line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
+            line["secondary"] = {"sampled_muzero_policy": secondary_sampled(args, B, S, device)}
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)
                 lanes = args.cpu_lanes or 192 * threads  # six runs, ~15 s of wall time in all
