@@ -423,8 +423,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       az_forward_prime_slots<0, 6>(first_unit, lane, regs);
       Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
       if (NOISY)
-        wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
-                                             need_keys ? sim_keys : nullptr);
+        wp = az_wave_chase_flagged<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
+                                               need_keys ? sim_keys : nullptr, [] {});
       else
         wp = az_wave_chase_lean(ws, h, j, sim, d.max_depth, active);
       AZ_SIM_STAMP(1);

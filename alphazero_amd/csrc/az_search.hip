@@ -198,9 +198,8 @@ AZ_UNROLL_K
     };
     WavePath wp;
     if (NOISY) {
-      wp = az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
-                                           need_keys ? sim_keys : nullptr);
-      prefetch();
+      wp = az_wave_chase_flagged<AMAX, KMAX>(c, l, s, b, h, j, sim, d.max_depth, active,
+                                             need_keys ? sim_keys : nullptr, prefetch);
     } else {
       wp = az_wave_chase_lean(s, h, j, sim, d.max_depth, active, prefetch);
     }

@@ -512,6 +512,24 @@ AZ_DEV WavePath az_wave_chase_noisy(const SearchCtx& c, const Lane<AMAX, KMAX>& 
   return w;
 }
 
+// Step 1 for the rules with per-visit noise.  A cached selection that the noise could change
+// carries a flag, and hardly any does (a few in a million): the walk is therefore the lean one,
+// flags ignored, and only when a flagged entry turns up on a path of the wave is the walk
+// repeated level by level with every flagged level decided by the exact rule.
+template <int AMAX, int KMAX, typename Between>
+AZ_DEV WavePath az_wave_chase_flagged(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s,
+                                      int b, int h, int j, int sim, int max_depth, bool active,
+                                      const uint32_t* sim_keys, Between&& between) {
+  WavePath w = az_wave_chase_lean(s, h, j, sim, max_depth, active, between);
+  bool flagged = active && j < w.dep && (w.e_mine & AZ_SEL_AMBIG) != 0;
+  for (int base = AZ_POS; base < w.dep_max; base += AZ_POS) {  // paths deeper than one pass
+    const int p = base + j;
+    flagged = flagged || (active && p < w.dep && (s.path[p] & AZ_SEL_AMBIG) != 0);
+  }
+  if (__builtin_amdgcn_ballot_w64(flagged) == 0) return w;
+  return az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, max_depth, active, sim_keys);
+}
+
 // The node the evaluation expands: parent = the last node of the path, action = the action
 // taken there, node = the child it leads to, or node `sim + 1` when that edge is unvisited
 // (search.py:97-99).  Valid in every thread of an active lane.
@@ -916,7 +934,7 @@ AZ_UNROLL_A
     const int child_code = sel_new & 0xffff;
     const int next_code = leaf ? 0 : (p == dep - 1 ? wl.node + 1 : w.e_mine_code);
     az_i32x4 entry = {sel_new, 0, 0, 0};
-    if (!NOISY) {
+    {
       const bool on_path = child_code != 0 && child_code == next_code;
       az_i32x4 stored;
       if (kEarlyEntries) {

@@ -16,7 +16,10 @@ rf = mctx.FusedRecurrentFn(model)
 logits, value = model.forward(st.obs)
 root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
 for _ in range(3):
-    mctx.gumbel_muzero_policy((), 0, root, rf, S)
+    if os.environ.get("VARIANT", "gumbel") == "sampled":
+        mctx.sampled_muzero_policy((), 0, root, rf, S, num_samples=100)
+    else:
+        mctx.gumbel_muzero_policy((), 0, root, rf, S)
 torch.cuda.synchronize()
 lib = nat.lib()
 buf = np.zeros((64, 16), np.int64)
