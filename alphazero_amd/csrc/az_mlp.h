@@ -612,14 +612,19 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
     AZ_WD(s.norm_std + 60, 2, b, lead, n_tab, 0);
     az_lds_barrier();
   }
+  // the unit whose weights the refills of unit ui fetch: the next one, or (past the last) the
+  // first one again / this one once more, so that the refill loads always have a valid source
+  auto ipre_of = [&](int ui) { return ui + 1 < n_tab ? ui + 1 : (WRAP ? 0 : ui); };
+  // The table word of a unit is read while the unit before it runs (the table does not change):
+  // behind the phase barrier only its broadcast into scalar registers is left.
+  uint32_t mine = n_tab > 0 ? az_mlp_table_read(s, wave, 0, ipre_of(0), lane) : 0u;
   for (int ui = 0; ui < n_tab; ++ui) {
     AZ_WD(s.norm_std + 60, 1, ui, n_tab, lead, 0);
-    // the unit whose weights the refills fetch: the next one, or (past the last) the first
-    // one again / this one once more, so that the refill loads always have a valid source
-    const int ipre = ui + 1 < n_tab ? ui + 1 : (WRAP ? 0 : ui);
     MlpUnit cur;
     MlpPre pre;
-    az_mlp_table_decode(az_mlp_table_read(s, wave, ui, ipre, lane), cur, pre);
+    az_mlp_table_decode(mine, cur, pre);
+    const int un = ui + 1 < n_tab ? ui + 1 : ui;
+    mine = az_mlp_table_read(s, wave, un, ipre_of(un), lane);
     AZ_STAMP_AT();
     az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
     AZ_STAMP_AT();
