@@ -174,8 +174,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   if (tid < 16 && b < B) az_store_obs<false>(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
-  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+  MlpFirst first;
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs, first, true);
+  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -237,8 +238,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   }
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
-  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+  MlpFirst first;
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs, first, true);
+  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
   __syncthreads();
   MlpRegs regs;
-  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs);
+  MlpFirst first;
+  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs, first, false);
   const bool need_keys = d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
   uint32_t r0 = d.key[0], r1 = d.key[1];
   long long depth_sum = 0;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
       az_store_obs<true>(md, s, tid, o.obs);
     }
     __syncthreads();
-    az_forward_tile<AZ_MLP_WAVES, true>(md, s, wave, lane, regs);
+    az_forward_tile<AZ_MLP_WAVES, true>(md, s, wave, lane, regs, first);
     if (active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) l.es[(size_t)node * 4 + i] = st.s[i];
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       // the end of the loop body, which needs them.
       // (in three portions, so that no wave sits in the queue behind 36 loads of each of
       // the other seven before it can start its walk)
-      const MlpPre first_unit = az_forward_prime_begin<AZ_MLP_WAVES>(s, wave, lane);
+      MlpFirst first;
+      const MlpPre first_unit = az_forward_prime_begin<AZ_MLP_WAVES>(s, wave, lane, first, true);
       az_forward_prime_slots<0, 6>(first_unit, lane, regs);
       Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
       if (NOISY)
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
-      az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs);
+      az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
       // Nothing is in flight any more (the row prefetch returned long ago), and saying so
       // here costs nothing.  Left unsaid, the compiler has to assume on some paths that the
       // prefetch is still pending when its registers are reused in the next simulation, and

@@ -497,36 +497,12 @@ AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpPre& next, MlpRegs& R, a
   }
 }
 
-AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
-                            az_f32x4& acc1, float* lds_base, int lane, int wave_, int& stamp_i) {
+// What a unit does with its accumulators: the rider's tile, and -- after the last round of
+// k-blocks -- the pair's tiles.
+AZ_DEV void az_mlp_unit_epilogue(const MlpUnit& u, const az_f32x4& acc0, const az_f32x4& acc1,
+                                 const az_f32x4& acc2, float bias0, float bias1, float bias2,
+                                 float* lds_base, int lane) {
   const bool two = u.flags & AZ_U_TWO, last = u.flags & AZ_U_LAST, rider = u.flags & AZ_U_RIDER;
-  if (u.flags & AZ_U_FIRST) {
-    acc0 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    acc1 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
-  az_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
-  // The biases are fetched BEFORE the refill loads are issued: vector loads return in
-  // order, so a bias load issued after them would drain the whole prefetch.
-  // All three are always loaded, for the same reason as the unconditional refills.
-  const float bias0 = az_ldg(u.o0.bias + (lane & 15));
-  const float bias1 = az_ldg(u.o0.bias + (two ? 16 : 0) + (lane & 15));
-  const float bias2 = az_ldg(u.o2.bias + (lane & 15));
-  const int lane_row = lane & 15, lane_q = lane >> 4;
-  const float* ap = lds_base + u.ap_off + lane_row * u.in_stride + lane_q * u.kpq;
-  const float* ap2 = lds_base + u.ap2_off + lane_row * u.in_stride2 + lane_q * u.kpq2;
-  __builtin_amdgcn_sched_barrier(0);
-  // Two waves share a SIMD.  Left alone they run their k-loops together (the matrix
-  // pipe is the bottleneck) and then their epilogues together (the vector ALU is).
-  // Priorities stagger them: the wave of the lower half multiplies first at the full
-  // MFMA rate, and its epilogue (lowest priority) then fills the issue slots between
-  // its partner's MFMAs.
-  if (wave_ < AZ_MLP_WAVES / 2)
-    __builtin_amdgcn_s_setprio(3);
-  else
-    __builtin_amdgcn_s_setprio(2);
-  az_mlp_unit_loop(u, next, R, acc0, acc1, acc2, ap, ap2, lane);
-  __builtin_amdgcn_s_setprio(0);
-  AZ_STAMP_AT();
   if (rider) az_mlp_tile_epilogue(u.o2, 0, acc2, bias2, lds_base, lane);
   if (!last) return;
   if (u.o0.act) {
@@ -558,16 +534,95 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az
   if (two) az_mlp_tile_epilogue(u.o0, 16, acc1, bias1, lds_base, lane);
 }
 
+
+AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
+                            az_f32x4& acc1, float* lds_base, int lane, int wave_, int& stamp_i) {
+  const bool two = u.flags & AZ_U_TWO, last = u.flags & AZ_U_LAST, rider = u.flags & AZ_U_RIDER;
+  if (u.flags & AZ_U_FIRST) {
+    acc0 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc1 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  az_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // The biases are fetched BEFORE the refill loads are issued: vector loads return in
+  // order, so a bias load issued after them would drain the whole prefetch.
+  // All three are always loaded, for the same reason as the unconditional refills.
+  const float bias0 = az_ldg(u.o0.bias + (lane & 15));
+  const float bias1 = az_ldg(u.o0.bias + (two ? 16 : 0) + (lane & 15));
+  const float bias2 = az_ldg(u.o2.bias + (lane & 15));
+  const int lane_row = lane & 15, lane_q = lane >> 4;
+  const float* ap = lds_base + u.ap_off + lane_row * u.in_stride + lane_q * u.kpq;
+  const float* ap2 = lds_base + u.ap2_off + lane_row * u.in_stride2 + lane_q * u.kpq2;
+  __builtin_amdgcn_sched_barrier(0);
+  // Two waves share a SIMD.  Left alone they run their k-loops together (the matrix
+  // pipe is the bottleneck) and then their epilogues together (the vector ALU is).
+  // Priorities stagger them: the wave of the lower half multiplies first at the full
+  // MFMA rate, and its epilogue (lowest priority) then fills the issue slots between
+  // its partner's MFMAs.
+  if (wave_ < AZ_MLP_WAVES / 2)
+    __builtin_amdgcn_s_setprio(3);
+  else
+    __builtin_amdgcn_s_setprio(2);
+  az_mlp_unit_loop(u, next, R, acc0, acc1, acc2, ap, ap2, lane);
+  __builtin_amdgcn_s_setprio(0);
+  AZ_STAMP_AT();
+  az_mlp_unit_epilogue(u, acc0, acc1, acc2, bias0, bias1, bias2, lds_base, lane);
+}
+
+// The wave's first unit when it is a single k-block (every network whose input is at most 16
+// wide starts so): its few weights and biases, fetched on their own.  Through the register slots
+// such a unit would cost a whole set of AZ_PRIME_LOADS loads of its own and, worse, would fetch
+// the NEXT unit's set -- a quarter of a megabyte per workgroup -- while it runs, with nothing to
+// hide that behind; handled directly, the slots can be primed with the second unit's weights
+// long before the networks start.
+struct MlpFirst {
+  az_f32x4 w0, w1, w2;
+  float bias0, bias1, bias2;
+  int direct;  // wave-uniform: the first unit runs from these registers, the slots hold the second unit
+};
+
 // Loads the weights of the wave's first unit; call before az_forward_tile (once, when
-// the calls wrap).  In two steps for callers that spread the 36 loads over other work:
-// az_forward_prime_begin fetches the refill fields, az_forward_prime_slots issues the loads of
-// the slots [KB0, KB1) -- every slot exactly once, in ascending order.
+// the calls wrap).  In two steps for callers that spread the loads over other work:
+// az_forward_prime_begin fetches the refill fields (and, with allow_direct, decides on the direct
+// form and requests its operands first of all), az_forward_prime_slots issues the loads of the
+// slots [KB0, KB1) -- every slot exactly once, in ascending order.
 template <int NWAVES>
-AZ_DEV MlpPre az_forward_prime_begin(const MlpLds& s, int wave, int lane) {
+AZ_DEV MlpPre az_forward_prime_begin(const MlpLds& s, int wave, int lane, MlpFirst& F, bool allow_direct) {
+  const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
+  const int lead = __builtin_amdgcn_readfirstlane(s.tab_n[NWAVES + wave]);
+  // lanes below AZ_UNIT_WORDS: the words of unit 0; lanes AZ_PRE_LANE0 ..: the refill fields of unit 1
+  const uint32_t mine = az_mlp_table_read(s, wave, 0, n_tab > 1 ? 1 : 0, lane);
+  auto word = [&](size_t byte_offset) { return (uint32_t)__builtin_amdgcn_readlane(mine, (int)(byte_offset / 4)); };
+  const int flags = (int)word(offsetof(MlpUnit, flags));
+  const int nkb = (int)word(offsetof(MlpUnit, nkb)), nkb2 = (int)word(offsetof(MlpUnit, nkb2));
+  F.direct = allow_direct && n_tab > 1 && lead == 0 && nkb == 1 && nkb2 <= 1 && (flags & AZ_U_FIRST) &&
+             (flags & AZ_U_LAST);
   MlpUnit unused;
   MlpPre cur;
-  az_mlp_table_decode(az_mlp_table_read(s, wave, 0, 0, lane), unused, cur);
-  cur.nkb = __builtin_amdgcn_readfirstlane(s.tab_n[wave]) > 0 ? cur.nkb : 0;  // 0: no unit, no loads
+  if (F.direct) {
+    auto ptr = [&](size_t byte_offset) {
+      const uint64_t lo = word(byte_offset), hi = word(byte_offset + 4);
+      return (lo | (hi << 32));
+    };
+    const az_f32x4* w0 = reinterpret_cast<const az_f32x4*>(ptr(offsetof(MlpUnit, w0)));
+    const az_f32x4* w1 = reinterpret_cast<const az_f32x4*>(ptr(offsetof(MlpUnit, w1)));
+    const az_f32x4* w2 = reinterpret_cast<const az_f32x4*>(ptr(offsetof(MlpUnit, w2)));
+    const float* b0 = reinterpret_cast<const float*>(ptr(offsetof(MlpUnit, o0) + offsetof(MlpTile, bias)));
+    const float* b2 = reinterpret_cast<const float*>(ptr(offsetof(MlpUnit, o2) + offsetof(MlpTile, bias)));
+    F.w0 = az_ldg4_lane(w0, lane);
+    F.w1 = az_ldg4_lane(w1, lane);
+    F.w2 = az_ldg4_lane(w2, lane);
+    F.bias0 = az_ldg(b0 + (lane & 15));
+    F.bias1 = az_ldg(b0 + ((flags & AZ_U_TWO) ? 16 : 0) + (lane & 15));
+    F.bias2 = az_ldg(b2 + (lane & 15));
+    az_mlp_table_decode(mine, unused, cur);  // (the refill fields of unit 1)
+  } else {
+    az_mlp_table_decode(az_mlp_table_read(s, wave, 0, 0, lane), unused, cur);
+    cur.nkb = n_tab > 0 ? cur.nkb : 0;  // 0: no unit, no loads
+    // (defined on this path too: left undefined they would count as carried over from the
+    // caller's previous simulation and be kept alive, or spilled, around its whole loop)
+    F.w0 = F.w1 = F.w2 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    F.bias0 = F.bias1 = F.bias2 = 0.0f;
+  }
   return cur;
 }
 
@@ -589,18 +644,44 @@ AZ_DEV void az_forward_prime_slots(const MlpPre& cur, int lane, MlpRegs& R) {
 }
 
 template <int NWAVES>
-AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
-  const MlpPre cur = az_forward_prime_begin<NWAVES>(s, wave, lane);
+AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R, MlpFirst& F,
+                             bool allow_direct) {
+  const MlpPre cur = az_forward_prime_begin<NWAVES>(s, wave, lane, F, allow_direct);
   az_forward_prime_slots<0, AZ_SLOTS>(cur, lane, R);
 }
 
+// The first unit in the direct form (MlpFirst): one k-block per tile out of F.
+AZ_DEV void az_mlp_first_unit(const MlpUnit& u, const MlpFirst& F, float* lds_base, int lane) {
+  const int lane_row = lane & 15, lane_q = lane >> 4;
+  const float* ap = lds_base + u.ap_off + lane_row * u.in_stride + lane_q * u.kpq;
+  const float* ap2 = lds_base + u.ap2_off + lane_row * u.in_stride2 + lane_q * u.kpq2;
+  const az_f32x4 a4 = *reinterpret_cast<const az_f32x4*>(ap);
+  const az_f32x4 a2 = *reinterpret_cast<const az_f32x4*>(ap2);
+  az_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f}, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, F.w0.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, F.w1.x, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, F.w2.x, acc2, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, F.w0.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, F.w1.y, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, F.w2.y, acc2, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, F.w0.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, F.w1.z, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, F.w2.z, acc2, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, F.w0.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, F.w1.w, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, F.w2.w, acc2, 0, 0, 0);
+  // (a unit without a rider has computed a tile nobody stores: same instructions for every unit)
+  az_mlp_unit_epilogue(u, acc0, acc1, acc2, F.bias0, F.bias1, F.bias2, lds_base, lane);
+}
+
 // Both networks on the 16 rows staged in s.in0 -> s.logits / s.value.  Called by all
-// NWAVES waves with the first unit's weights in R (az_forward_prime); every wave passes one
+// NWAVES waves with the first unit's weights in R / F (az_forward_prime); every wave passes one
 // workgroup barrier per phase, the last of which makes the results visible to every thread.
 // With WRAP the last unit prefetches the first unit's weights again, so the next call needs
-// no priming.
+// no priming (and the direct form of the first unit is not used).
 template <int NWAVES, bool WRAP>
-AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R) {
+AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R,
+                            const MlpFirst& F) {
   const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
   const int lead = __builtin_amdgcn_readfirstlane(s.tab_n[NWAVES + wave]);
   az_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -615,10 +696,24 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
   // the unit whose weights the refills of unit ui fetch: the next one, or (past the last) the
   // first one again / this one once more, so that the refill loads always have a valid source
   auto ipre_of = [&](int ui) { return ui + 1 < n_tab ? ui + 1 : (WRAP ? 0 : ui); };
+  const int first = !WRAP && F.direct ? 1 : 0;
+  if (first) {
+    MlpUnit u0;
+    MlpPre unused;
+    az_mlp_table_decode(az_mlp_table_read(s, wave, 0, 0, lane), u0, unused);
+    AZ_STAMP_AT();
+    az_mlp_first_unit(u0, F, s.base, lane);
+    AZ_STAMP_AT();
+    for (int b = 0; b < u0.bars; ++b) {
+      AZ_WD(s.norm_std + 60, 3, b, u0.bars, 0, n_tab);
+      az_lds_barrier();
+    }
+    AZ_STAMP_AT();
+  }
   // The table word of a unit is read while the unit before it runs (the table does not change):
   // behind the phase barrier only its broadcast into scalar registers is left.
-  uint32_t mine = n_tab > 0 ? az_mlp_table_read(s, wave, 0, ipre_of(0), lane) : 0u;
-  for (int ui = 0; ui < n_tab; ++ui) {
+  uint32_t mine = n_tab > first ? az_mlp_table_read(s, wave, first, ipre_of(first), lane) : 0u;
+  for (int ui = first; ui < n_tab; ++ui) {
     AZ_WD(s.norm_std + 60, 1, ui, n_tab, lead, 0);
     MlpUnit cur;
     MlpPre pre;
