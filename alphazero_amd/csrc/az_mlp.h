@@ -65,6 +65,7 @@ struct ModelDev {
   float gamma;
   int obs_dim, A, K;
   int pol_kp, val_kp;  // widest padded layer of each network
+  int tab_units;       // units of the busiest wave in one pass over both networks (table rows per wave)
   MlpLayout pol, val;
   const float* packed;
   const float* mean;
@@ -105,12 +106,13 @@ AZ_DEV int az_act_index(int k, int kp) { return (k & 3) * (kp >> 2) + (k >> 2); 
 
 // LDS floats of the network scratch: in0 [16][AZ_IN0_STRIDE], two ping-pong activation buffers
 // per network, logits [16][AZ_MAX_ACTIONS], values [16][AZ_MAX_ATOMS], the unit table
-// [AZ_MLP_WAVES][AZ_TABLE_UNITS][AZ_UNIT_WORDS], its per-wave counts, and the observation
-// normaliser's mean and standard deviation.
-__host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp) {
+// [AZ_MLP_WAVES][tab_units][AZ_UNIT_WORDS] (tab_units = the units of the busiest wave of this
+// model, at most AZ_TABLE_UNITS), its per-wave counts, and the observation normaliser's mean
+// and standard deviation.
+__host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp, int tab_units) {
   return 16 * AZ_IN0_STRIDE + 2 * 16 * az_act_stride(pol_kp) + 2 * 16 * az_act_stride(val_kp) +
          16 * AZ_MAX_ACTIONS + 16 * AZ_MAX_ATOMS +
-         AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS + 16 + 2 * AZ_IN0_STRIDE;
+         AZ_MLP_WAVES * tab_units * AZ_UNIT_WORDS + 16 + 2 * AZ_IN0_STRIDE;
 }
 
 struct MlpLds {
@@ -119,7 +121,9 @@ struct MlpLds {
   int32_t* tab_n;  // units of each wave in the table, or -1 when they do not fit
   float *norm_mean, *norm_std;  // [obs_dim] copies of the observation normaliser
   int pstride, vstride;
-  AZ_DEV MlpLds(float* base_, int pol_kp, int val_kp) {
+  int tab_units;  // rows of the table per wave
+  AZ_DEV MlpLds(float* base_, int pol_kp, int val_kp, int tab_units_) {
+    tab_units = tab_units_;
     base = base_;
     pstride = az_act_stride(pol_kp);
     vstride = az_act_stride(val_kp);
@@ -131,7 +135,7 @@ struct MlpLds {
     logits = vb + 16 * vstride;
     value = logits + 16 * AZ_MAX_ACTIONS;
     tab = reinterpret_cast<uint32_t*>(value + 16 * AZ_MAX_ATOMS);
-    tab_n = reinterpret_cast<int32_t*>(tab + AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS);
+    tab_n = reinterpret_cast<int32_t*>(tab + AZ_MLP_WAVES * tab_units * AZ_UNIT_WORDS);
     norm_mean = reinterpret_cast<float*>(tab_n + 16);
     norm_std = norm_mean + AZ_IN0_STRIDE;
   }
@@ -288,18 +292,24 @@ __host__ __device__ inline int az_mlp_phases(const ModelDev& md) {
   return md.pol.n_layers > md.val.n_layers ? md.pol.n_layers : md.val.n_layers;
 }
 
-// Units the busiest wave (wave 0) runs in one pass over both networks; the schedule table
-// holds AZ_TABLE_UNITS per wave, and the host refuses models that need more.
+// Units the busiest wave runs in one pass over both networks (a wave's items are idx = wave,
+// wave + AZ_MLP_WAVES, ...; value and policy items of a phase can take different numbers of
+// rounds, so the busiest wave is not always wave 0); the schedule table holds that many per wave
+// (ModelDev::tab_units); the host refuses models that need more than AZ_TABLE_UNITS.
 inline int az_mlp_units_per_wave(const ModelDev& md) {
-  int units = 0;
-  for (int phase = 0; phase < az_mlp_phases(md); ++phase) {
-    const PhaseShape ps = az_phase_shape(md, phase);
-    for (int idx = 0; idx < ps.n; idx += AZ_MLP_WAVES) {
-      const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
-      units += ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
+  int most = 0;
+  for (int wave = 0; wave < AZ_MLP_WAVES; ++wave) {
+    int units = 0;
+    for (int phase = 0; phase < az_mlp_phases(md); ++phase) {
+      const PhaseShape ps = az_phase_shape(md, phase);
+      for (int idx = wave; idx < ps.n; idx += AZ_MLP_WAVES) {
+        const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
+        units += ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
+      }
     }
+    most = units > most ? units : most;
   }
-  return units;
+  return most;
 }
 
 // Writes the wave's unit sequence into the LDS table (every wave calls it; the caller
@@ -314,14 +324,14 @@ AZ_DEV void az_mlp_table_build(const ModelDev& md, const MlpLds& s, int wave, in
   while (u.flags & AZ_U_VALID) {
     const MlpUnit nx = az_mlp_next_unit<NWAVES>(md, s, P, u.phase, u.idx, u.round, false, wave);
     u.bars = nx.phase - u.phase;  // past the last unit: nx.phase == P
-    if (n < AZ_TABLE_UNITS && lane == 0)
-      *reinterpret_cast<MlpUnit*>(s.tab + (size_t)(wave * AZ_TABLE_UNITS + n) * AZ_UNIT_WORDS) = u;
+    if (n < s.tab_units && lane == 0)
+      *reinterpret_cast<MlpUnit*>(s.tab + (size_t)(wave * s.tab_units + n) * AZ_UNIT_WORDS) = u;
     ++n;
     u = nx;
   }
   if (lane == 0) {
-    s.tab_n[wave] = n <= AZ_TABLE_UNITS ? n : 0;
-    s.tab_n[NWAVES + wave] = n <= AZ_TABLE_UNITS ? lead : P;
+    s.tab_n[wave] = n <= s.tab_units ? n : 0;
+    s.tab_n[NWAVES + wave] = n <= s.tab_units ? lead : P;
   }
 }
 
@@ -335,7 +345,7 @@ AZ_DEV uint32_t az_mlp_table_read(const MlpLds& s, int wave, int i, int ipre, in
   int word = 0;
   if (lane < AZ_UNIT_WORDS) word = i * AZ_UNIT_WORDS + lane;
   if (pw >= 0 && pw < 8) word = ipre * AZ_UNIT_WORDS + pre_word;
-  return s.tab[wave * (AZ_TABLE_UNITS * AZ_UNIT_WORDS) + word];
+  return s.tab[wave * (s.tab_units * AZ_UNIT_WORDS) + word];
 }
 
 // The words broadcast into scalar registers.  The weight pointers of the running unit are

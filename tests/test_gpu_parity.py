@@ -196,6 +196,28 @@ def test_forward_and_recurrent_step_vs_oracle(hip, oracle, env_id):
         assert np.array_equal(out.value.cpu().numpy(), rv)
 
 
+@pytest.mark.parametrize("policy_hidden,value_hidden,K", [
+    ((33, 1024, 64), (32, 48, 16, 48), 1),     # the policy's items take more rounds than the value's:
+    ((48, 600, 128, 64), (100, 200), 1),       # a wave other than wave 0 runs the most units
+    ((1, 48, 600, 17), (17, 16, 16, 32), 64),
+    ((), (), 1),                                # one layer each: the first unit is also the last
+])
+def test_forward_network_shapes_vs_oracle(hip, oracle, policy_hidden, value_hidden, K):
+    """Forward pass of unusual network shapes (found by tests/fuzz_forward.py) against the checker."""
+    rng = np.random.default_rng(9)
+    env_id = "MountainCar-v0"
+    case = runners.synthetic_case("gumbel", B=37, S=1, K=K, seed=9, env_id=env_id, random_bias=True,
+                                  policy_hidden=policy_hidden, value_hidden=value_hidden)
+    model = case["model"]
+    fm = hip.make_model(model)
+    md = oracle.make_model(env_id, model["policy_layers"], model["value_layers"], model["mean"],
+                           model["std"])
+    obs = rng.uniform(-2, 2, (37, 2)).astype(np.float32)
+    lg, val = fm.forward(hip.dev(obs))
+    rl, rv = oracle.forward(md, obs)
+    assert np.array_equal(lg.cpu().numpy(), rl) and np.array_equal(val.cpu().numpy(), rv)
+
+
 FUSED_CASES = [
     ("CartPole-v1", "gumbel", 40, 16, 1, {}),
     ("CartPole-v1", "gumbel", 20, 256, 1, {}),   # the S of the largest baseline configuration
