@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--sims", type=int, default=64)
     p.add_argument("--env", default="CartPole-v1")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="leave out the sampled_muzero_policy row (profiling runs: one search kernel only)")
     p.add_argument("--cpu-lanes", type=int, default=0, help="lanes of the CPU baseline sample")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="all ranks share cuda:0 and reduce over gloo (checks the N > 1 code path "
@@ -309,7 +311,8 @@ def main():
         }
         if world == 1:
             line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
-            line["secondary"] = {"sampled_muzero_policy": secondary_sampled(args, B, S, device)}
+            if not args.no_secondary:
+                line["secondary"] = {"sampled_muzero_policy": secondary_sampled(args, B, S, device)}
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)
                 lanes = args.cpu_lanes or 192 * threads  # six runs, ~15 s of wall time in all
