@@ -111,13 +111,15 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   md->packed = m->packed;
   md->mean = m->norm_mean;
   md->std = m->norm_std;
+  md->head_floats = 0;
+  md->head_floats = az_mlp_head_floats(*md);  // (before anything that depends on the unit phases)
   md->tab_units = az_mlp_units_per_wave(*md) > 0 ? az_mlp_units_per_wave(*md) : 1;
   if (az_mlp_units_per_wave(*md) > AZ_TABLE_UNITS)
     return az_fail(AZ_ERR_UNSUPPORTED,
                    "the networks need %d work units per wave, the schedule table holds %d "
                    "(fewer or narrower layers, or a recurrent_fn in Python through the callback path)",
                    az_mlp_units_per_wave(*md), AZ_TABLE_UNITS);
-  if ((size_t)az_mlp_lds_floats(pk, vk, md->tab_units) * 4 > 160 * 1024)
+  if ((size_t)az_mlp_lds_floats(pk, vk, md->tab_units, md->head_floats) * 4 > 160 * 1024)
     return az_fail(AZ_ERR_UNSUPPORTED, "layer widths %d / %d need more than 160 KiB of LDS", pk, vk);
   return AZ_OK;
 }
@@ -159,6 +161,7 @@ AZ_DEV void az_stage_inputs(const ModelDev& md, const MlpLds& s, int tid, int nt
     s.norm_mean[i] = md.mean[i];
     s.norm_std[i] = md.std[i];
   }
+  az_mlp_stage_heads(md, s, tid, nthreads);
 }
 
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
@@ -195,7 +198,7 @@ extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float*
   ModelDev md;
   if (int rc = az_model_dev(m, &md)) return rc;
   if (B < 1 || !obs || !logits || !value) return az_fail(AZ_ERR_INVALID, "bad forward arguments");
-  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
   if (int rc = az_set_lds((const void*)k_forward, lds)) return rc;
   k_forward<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
       md, B, obs, logits, value);
@@ -255,7 +258,7 @@ extern "C" int az_recurrent_step(const az_model* m, int32_t B, float* state, int
   if (int rc = az_model_dev(m, &md)) return rc;
   if (B < 1 || !state || !time || !action || !reward || !discount || !logits || !value)
     return az_fail(AZ_ERR_INVALID, "bad recurrent_step arguments");
-  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
   if (int rc = az_set_lds((const void*)k_recurrent_step, lds)) return rc;
   k_recurrent_step<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
       md, B, state, time, action, reward, discount, logits, value);
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   const az_search_desc& d = c.d;
   const int A = EXACT ? AMAX : d.A, K = EXACT ? KMAX : d.K, S = d.S;
   MlpLds s(lds, md.pol_kp, md.val_kp, md.tab_units);
-  float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units);
+  float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
@@ -538,7 +541,7 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   if (d->A != md.A || d->K != md.K)
     return az_fail(AZ_ERR_INVALID, "search A=%d K=%d do not match the model's A=%d K=%d", d->A,
                    d->K, md.A, md.K);
-  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units) * 4;
+  const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, lds, false)) {
     size_t lds2 = lds + ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)az_key_words(d->S)) * 4;

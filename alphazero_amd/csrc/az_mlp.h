@@ -66,6 +66,7 @@ struct ModelDev {
   int obs_dim, A, K;
   int pol_kp, val_kp;  // widest padded layer of each network
   int tab_units;       // units of the busiest wave in one pass over both networks (table rows per wave)
+  int head_floats;     // LDS floats of the output heads' staged weights (az_mlp_head_floats), 0: not used
   MlpLayout pol, val;
   const float* packed;
   const float* mean;
@@ -107,12 +108,12 @@ AZ_DEV int az_act_index(int k, int kp) { return (k & 3) * (kp >> 2) + (k >> 2); 
 // LDS floats of the network scratch: in0 [16][AZ_IN0_STRIDE], two ping-pong activation buffers
 // per network, logits [16][AZ_MAX_ACTIONS], values [16][AZ_MAX_ATOMS], the unit table
 // [AZ_MLP_WAVES][tab_units][AZ_UNIT_WORDS] (tab_units = the units of the busiest wave of this
-// model, at most AZ_TABLE_UNITS), its per-wave counts, and the observation normaliser's mean
-// and standard deviation.
-__host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp, int tab_units) {
+// model, at most AZ_TABLE_UNITS), its per-wave counts, the observation normaliser's mean
+// and standard deviation, and the staged weights of small output heads (az_mlp_head_floats).
+__host__ __device__ inline int az_mlp_lds_floats(int pol_kp, int val_kp, int tab_units, int head_floats) {
   return 16 * AZ_IN0_STRIDE + 2 * 16 * az_act_stride(pol_kp) + 2 * 16 * az_act_stride(val_kp) +
          16 * AZ_MAX_ACTIONS + 16 * AZ_MAX_ATOMS +
-         AZ_MLP_WAVES * tab_units * AZ_UNIT_WORDS + 16 + 2 * AZ_IN0_STRIDE;
+         AZ_MLP_WAVES * tab_units * AZ_UNIT_WORDS + 16 + 2 * AZ_IN0_STRIDE + head_floats;
 }
 
 struct MlpLds {
@@ -120,6 +121,7 @@ struct MlpLds {
   uint32_t* tab;   // unit table; 16-byte aligned because every region is a multiple of 4 floats
   int32_t* tab_n;  // units of each wave in the table, or -1 when they do not fit
   float *norm_mean, *norm_std;  // [obs_dim] copies of the observation normaliser
+  float* head_w;                // staged output heads (az_mlp_heads)
   int pstride, vstride;
   int tab_units;  // rows of the table per wave
   AZ_DEV MlpLds(float* base_, int pol_kp, int val_kp, int tab_units_) {
@@ -138,6 +140,7 @@ struct MlpLds {
     tab_n = reinterpret_cast<int32_t*>(tab + AZ_MLP_WAVES * tab_units * AZ_UNIT_WORDS);
     norm_mean = reinterpret_cast<float*>(tab_n + 16);
     norm_std = norm_mean + AZ_IN0_STRIDE;
+    head_w = norm_std + AZ_IN0_STRIDE;
   }
 };
 
@@ -292,6 +295,34 @@ __host__ __device__ inline int az_mlp_phases(const ModelDev& md) {
   return md.pol.n_layers > md.val.n_layers ? md.pol.n_layers : md.val.n_layers;
 }
 
+// LDS floats for the output heads when the last phase consists of small output heads only (at
+// most AZ_MLP_WAVES output columns between them; a network that ends earlier has nothing in
+// that phase), else 0.  Such a phase is a handful of matrix-vector products: as a unit of the
+// matrix pipe it would occupy one wave (which multiplies its single tile twice, the loop always
+// running two accumulators) while seven wait at the last barrier; it runs on the vector ALU
+// instead, one wave per output column (az_mlp_heads), from weights staged once per kernel in
+// LDS, and the unit machinery covers the phases before it.  Per head: nout columns of kp
+// weights + 16 biases.
+#define AZ_HEAD_MAX_FLOATS 1024
+__host__ __device__ inline int az_mlp_head_floats(const ModelDev& md) {
+  const int P = az_mlp_phases(md);
+  if (P < 2) return 0;
+  int total = 0, items = 0;
+  for (int net = 0; net < 2; ++net) {
+    const MlpLayout& L = net ? md.val : md.pol;
+    if (L.n_layers < P) continue;
+    if (L.np[P - 1] != 16) return 0;
+    total += L.nout[P - 1] * L.kp[P - 1] + 16;
+    items += L.nout[P - 1];
+  }
+  return total <= AZ_HEAD_MAX_FLOATS && items <= AZ_MLP_WAVES ? total : 0;
+}
+__host__ __device__ inline bool az_mlp_heads_apply(const ModelDev& md) { return md.head_floats > 0; }
+// phases that run as units of the matrix pipe
+__host__ __device__ inline int az_mlp_unit_phases(const ModelDev& md) {
+  return az_mlp_phases(md) - (az_mlp_heads_apply(md) ? 1 : 0);
+}
+
 // Units the busiest wave runs in one pass over both networks (a wave's items are idx = wave,
 // wave + AZ_MLP_WAVES, ...; value and policy items of a phase can take different numbers of
 // rounds, so the busiest wave is not always wave 0); the schedule table holds that many per wave
@@ -300,7 +331,7 @@ inline int az_mlp_units_per_wave(const ModelDev& md) {
   int most = 0;
   for (int wave = 0; wave < AZ_MLP_WAVES; ++wave) {
     int units = 0;
-    for (int phase = 0; phase < az_mlp_phases(md); ++phase) {
+    for (int phase = 0; phase < az_mlp_unit_phases(md); ++phase) {
       const PhaseShape ps = az_phase_shape(md, phase);
       for (int idx = wave; idx < ps.n; idx += AZ_MLP_WAVES) {
         const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
@@ -317,7 +348,7 @@ inline int az_mlp_units_per_wave(const ModelDev& md) {
 // units, tab_n[NWAVES + wave] = phase barriers the wave passes before its first unit.
 template <int NWAVES>
 AZ_DEV void az_mlp_table_build(const ModelDev& md, const MlpLds& s, int wave, int lane) {
-  const int P = az_mlp_phases(md);
+  const int P = az_mlp_unit_phases(md);  // (the barrier counts below end where the heads begin)
   int n = 0;
   MlpUnit u = az_mlp_next_unit<NWAVES>(md, s, P, 0, 0, 0, true, wave);
   const int lead = u.phase;  // P when the wave has no unit at all
@@ -681,6 +712,135 @@ AZ_DEV void az_mlp_first_unit(const MlpUnit& u, const MlpFirst& F, float* lds_ba
   az_mlp_unit_epilogue(u, acc0, acc1, acc2, F.bias0, F.bias1, F.bias2, lds_base, lane);
 }
 
+// Offsets of a network's head in MlpLds::head_w: [nout][kp] weights in the permuted order of the
+// activations (az_act_index), then 16 biases; the policy's head first.
+AZ_DEV int az_mlp_head_offset(const ModelDev& md, bool is_val) {
+  const int P = az_mlp_phases(md);
+  if (!is_val || md.pol.n_layers < P) return 0;
+  return md.pol.nout[P - 1] * md.pol.kp[P - 1] + 16;
+}
+
+// Kernel prologue (with az_stage_inputs): the heads' weights from the packed buffer (tile 0 of
+// the last layer: word ((kb * 64 + (k & 3) * 16 + col) * 4 + ((k >> 2) & 3)) holds w[k][col]).
+AZ_DEV void az_mlp_stage_heads(const ModelDev& md, const MlpLds& s, int tid, int nthreads) {
+  if (!az_mlp_heads_apply(md)) return;
+  const int P = az_mlp_phases(md);
+  for (int net = 0; net < 2; ++net) {
+    const MlpLayout& L = net ? md.val : md.pol;
+    if (L.n_layers < P) continue;
+    const int kp = L.kp[P - 1], nout = L.nout[P - 1];
+    float* dst = s.head_w + az_mlp_head_offset(md, net != 0);
+    const float* w = md.packed + L.w_off[P - 1];
+    for (int i = tid; i < nout * kp; i += nthreads) {
+      const int col = i / kp, k = i - col * kp;
+      dst[col * kp + az_act_index(k, kp)] = w[(((k >> 4) * 64 + (k & 3) * 16 + col) * 4) + ((k >> 2) & 3)];
+    }
+    for (int i = tid; i < 16; i += nthreads) dst[nout * kp + i] = i < nout ? md.packed[L.b_off[P - 1] + i] : 0.0f;
+  }
+}
+
+// One column of an output head on the vector ALU: the wave's lanes own the 16 rows (lane & 15;
+// all 64 lanes run, which a lone wave does faster than 16 of them) and run each element's
+// k-ordered chain of fused multiply-adds -- the operations, in the order, of the matrix
+// instruction that would otherwise compute it.  Activations and staged weights are in the same
+// permuted order: one 16-byte read at m * kp / 4 + 4 kb holds k = 16 kb + m + {0, 4, 8, 12}, four
+// of each cover a k-block.  With the width known at compile time (KP > 0) every read is the
+// lane's base address plus an immediate; the loop then consists of reads and the chain only,
+// which is what bounds a lone wave: it issues one instruction per 4 to 6 cycles.
+template <int KP>
+AZ_DEV float az_mlp_head_chain(const float* arow, const float* wcol, int kp_runtime) {
+  const int kp = KP > 0 ? KP : kp_runtime, kpq = kp >> 2, nkb = kp >> 4;
+  struct Blk {
+    az_f32x4 a0, a1, a2, a3, w0, w1, w2, w3;
+  };
+  auto read_blk = [&](int kb) {
+    Blk b;
+    b.a0 = *reinterpret_cast<const az_f32x4*>(arow + 4 * kb);
+    b.a1 = *reinterpret_cast<const az_f32x4*>(arow + kpq + 4 * kb);
+    b.a2 = *reinterpret_cast<const az_f32x4*>(arow + 2 * kpq + 4 * kb);
+    b.a3 = *reinterpret_cast<const az_f32x4*>(arow + 3 * kpq + 4 * kb);
+    b.w0 = *reinterpret_cast<const az_f32x4*>(wcol + 4 * kb);
+    b.w1 = *reinterpret_cast<const az_f32x4*>(wcol + kpq + 4 * kb);
+    b.w2 = *reinterpret_cast<const az_f32x4*>(wcol + 2 * kpq + 4 * kb);
+    b.w3 = *reinterpret_cast<const az_f32x4*>(wcol + 3 * kpq + 4 * kb);
+    return b;
+  };
+  float acc = 0.0f;
+#define AZ_HEAD_STEP(B, c)                     \
+  acc = __builtin_fmaf(B.a0.c, B.w0.c, acc);   \
+  acc = __builtin_fmaf(B.a1.c, B.w1.c, acc);   \
+  acc = __builtin_fmaf(B.a2.c, B.w2.c, acc);   \
+  acc = __builtin_fmaf(B.a3.c, B.w3.c, acc)
+#define AZ_HEAD_BLOCK(B) \
+  AZ_HEAD_STEP(B, x);    \
+  AZ_HEAD_STEP(B, y);    \
+  AZ_HEAD_STEP(B, z);    \
+  AZ_HEAD_STEP(B, w)
+  // Two k-blocks per turn, each read while the other is multiplied (the fences keep the
+  // compiler from folding the halves back into read-wait-multiply); whole pairs without a
+  // branch inside: a conditional chain would draw the reads issued before it into its own arm.
+  Blk even = read_blk(0);
+  int kb = 0;
+  if constexpr (KP > 0) {
+#pragma unroll
+    for (; kb + 2 <= nkb; kb += 2) {
+      const Blk odd = read_blk(kb + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      AZ_HEAD_BLOCK(even);
+      __builtin_amdgcn_sched_barrier(0);
+      even = read_blk(kb + 2 < nkb ? kb + 2 : kb);
+      __builtin_amdgcn_sched_barrier(0);
+      AZ_HEAD_BLOCK(odd);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll 1
+    for (; kb + 2 <= nkb; kb += 2) {
+      const Blk odd = read_blk(kb + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      AZ_HEAD_BLOCK(even);
+      __builtin_amdgcn_sched_barrier(0);
+      even = read_blk(kb + 2 < nkb ? kb + 2 : kb);
+      __builtin_amdgcn_sched_barrier(0);
+      AZ_HEAD_BLOCK(odd);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (kb < nkb) {
+    AZ_HEAD_BLOCK(even);
+  }
+#undef AZ_HEAD_BLOCK
+#undef AZ_HEAD_STEP
+  return acc;
+}
+
+// The output heads of the last phase on the vector ALU (az_mlp_heads_apply): every output column
+// of the two heads is one item, taken by one wave (az_mlp_head_chain).
+AZ_DEV void az_mlp_heads(const ModelDev& md, const MlpLds& s, int wave, int lane) {
+  const int phase = az_mlp_phases(md) - 1;
+  const bool has_v = md.val.n_layers == phase + 1, has_p = md.pol.n_layers == phase + 1;
+  const int nout_v = has_v ? md.val.nout[phase] : 0, nout_p = has_p ? md.pol.nout[phase] : 0;
+  const int kp_v = has_v ? md.val.kp[phase] : 16, kp_p = has_p ? md.pol.kp[phase] : 16;
+  const int in_v = (int)(((phase & 1) ? s.va : s.vb) - s.base), in_p = (int)(((phase & 1) ? s.pa : s.pb) - s.base);
+  const int out_v = (int)(s.value - s.base), out_p = (int)(s.logits - s.base);
+  const int n_items = nout_p + nout_v;
+  const int row = lane & 15;
+  for (int item = __builtin_amdgcn_readfirstlane(wave); item < n_items; item += AZ_MLP_WAVES) {
+    const bool is_val = item >= nout_p;
+    const int col = is_val ? item - nout_p : item;
+    const int kp = is_val ? kp_v : kp_p;
+    const float* arow = s.base + (is_val ? in_v : in_p) + row * (is_val ? s.vstride : s.pstride);
+    const float* head = s.head_w + (is_val && has_p ? nout_p * kp_p + 16 : 0);
+    const float* wcol = head + col * kp;
+    const float acc = kp == 256  ? az_mlp_head_chain<256>(arow, wcol, kp)
+                      : kp == 128 ? az_mlp_head_chain<128>(arow, wcol, kp)
+                      : kp == 64  ? az_mlp_head_chain<64>(arow, wcol, kp)
+                                  : az_mlp_head_chain<0>(arow, wcol, kp);
+    const float bias = head[(is_val ? nout_v : nout_p) * kp + col];
+    if (lane < 16) s.base[(is_val ? out_v + row * AZ_MAX_ATOMS : out_p + row * AZ_MAX_ACTIONS) + col] = acc + bias;
+  }
+}
+
 // Both networks on the 16 rows staged in s.in0 -> s.logits / s.value.  Called by all
 // NWAVES waves with the first unit's weights in R / F (az_forward_prime); every wave passes one
 // workgroup barrier per phase, the last of which makes the results visible to every thread.
@@ -725,6 +885,12 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
     MlpUnit cur;
     MlpPre pre;
     az_mlp_table_decode(mine, cur, pre);
+    if (!WRAP && ui == n_tab - 1) {
+      // nothing follows the last unit: its refills (their number is fixed) all fetch one and the
+      // same k-block instead of a whole set of weights that nobody would use
+      pre.nkb = 1;
+      pre.nkb2 = pre.nkb2 > 0 ? 1 : 0;
+    }
     const int un = ui + 1 < n_tab ? ui + 1 : ui;
     mine = az_mlp_table_read(s, wave, un, ipre_of(un), lane);
     AZ_STAMP_AT();
@@ -735,6 +901,11 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
       az_lds_barrier();
     }
     AZ_STAMP_AT();
+  }
+  if (az_mlp_heads_apply(md)) {
+    az_mlp_heads(md, s, wave, lane);
+    AZ_STAMP_AT();
+    az_lds_barrier();
   }
 }
 

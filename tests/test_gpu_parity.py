@@ -201,6 +201,12 @@ def test_forward_and_recurrent_step_vs_oracle(hip, oracle, env_id):
     ((48, 600, 128, 64), (100, 200), 1),       # a wave other than wave 0 runs the most units
     ((1, 48, 600, 17), (17, 16, 16, 32), 64),
     ((), (), 1),                                # one layer each: the first unit is also the last
+    # output heads that run on the vector ALU (at most 8 output columns in the last phase):
+    ((64,), (64,), 1),                          # both heads in the last phase, 4 k-blocks each
+    ((128, 48), (32, 128), 1),                  # an odd number of k-blocks (3) and 8 of them
+    ((256,), (16,), 4),                         # 3 actions + 4 atoms = 7 columns; 16 k-blocks and a single one
+    ((32, 32), (256,), 1),                      # only the policy's head is in the last phase
+    ((100,), (100,), 8),                        # 11 columns: stays on the matrix pipe
 ])
 def test_forward_network_shapes_vs_oracle(hip, oracle, policy_hidden, value_hidden, K):
     """Forward pass of unusual network shapes (found by tests/fuzz_forward.py) against the checker."""
