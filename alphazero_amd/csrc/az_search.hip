@@ -168,6 +168,29 @@ AZ_UNROLL_K
     reward = inj.reward[e];
     discount = inj.discount[e];
   }
+  // Gumbel rules with the tree in LDS: max(tiny, softmax(prior logits)) of every node the search
+  // can create is worked out here, one node per thread, instead of by all the path's threads in
+  // every simulation -- node n > 0 takes the prior logits of evaluation n - 1.
+  constexpr bool cache_probs = TREE_LDS && RULE == 1;
+  float* const node_probs =
+      cache_probs ? reinterpret_cast<float*>(sim_keys + az_key_words(S)) + TreeLds::words(S + 1, A, K) +
+                        (size_t)ln * (S + 1) * A
+                  : nullptr;
+  if (cache_probs) {
+    const size_t bb = active ? b : 0;
+    for (int n = j; n <= S; n += AZ_POS) {
+      const float* src = n == 0 ? t.children_prior_logits + bb * (S + 1) * A
+                                : inj.prior_logits + (bb * S + (n - 1)) * A;
+      float lg[AMAX], pr[AMAX];
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < A) lg[a] = src[a];
+      az_prior_probs<AMAX>(lg, A, pr);
+AZ_UNROLL_A
+      for (int a = 0; a < AZ_TRIP_A; ++a)
+        if (a < A) node_probs[n * A + a] = pr[a];
+    }
+  }
   if (tree_in_lds) tl.template copy<true>(t, b0, lanes_here, tid, blockDim.x);
   const az_tree tv = tree_in_lds ? tl.view() : t;
   Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
@@ -206,7 +229,7 @@ AZ_UNROLL_K
     if (j == 0) depth_sum += wp.dep;
     AZ_TREE_STAMP(2);
     az_wave_update<AMAX, KMAX, NOISY, RULE == 1>(c, l, s, active, h, j, sim, wp, ev_logits, ev_value, reward,
-                                      discount);
+                                      discount, nullptr, node_probs);
     AZ_TREE_STAMP(7);
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a) ev_logits[a] = nx_logits[a];
@@ -249,11 +272,13 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
   SearchCtx c{*d, *in};
   if (az_coop_applicable(d, 0, false)) {
     size_t lds = az_wave_lds_bytes(d);
-    const size_t tree_bytes = TreeLds::words(d->S + 1, d->A, d->K) * 4;
+    const int rule = az_rule_of(d);
+    // (the tree's copy, and behind it the Gumbel rules' per-node prior probabilities)
+    const size_t tree_bytes =
+        (TreeLds::words(d->S + 1, d->A, d->K) + (rule == 1 ? (size_t)AZ_WG_LANES * (d->S + 1) * d->A : 0)) * 4;
     const int tree_in_lds = lds + tree_bytes <= 160 * 1024;
     if (tree_in_lds) lds += tree_bytes;
     const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
-    const int rule = az_rule_of(d);
     return az_dispatch_coop(d->A, d->K, [&]<int AMAX, int KMAX, bool EXACT>() -> int {
       using Kern = void (*)(SearchCtx, az_tree, az_injected, unsigned long long*);
       Kern kern;

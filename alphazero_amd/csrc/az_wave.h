@@ -615,10 +615,28 @@ AZ_DEV float az_pin(float x) {
 }
 
 // vis: the children's visit counts AFTER this simulation's backup (they are known from the path).
+// The prior part of the rule, max(tiny, softmax(prior logits)) (qtransforms.py:121-123): a
+// function of the node's prior logits alone, which change only when the node is expanded.
+template <int AMAX>
+AZ_DEV void az_prior_probs(const float (&logits)[AMAX], int A, float (&probs)[AMAX]) {
+  az_softmax_fast<AMAX>(logits, A, probs);
+AZ_UNROLL_A
+  for (int a = 0; a < AZ_TRIP_A; ++a)
+    if (a < A) probs[a] = az_max_nan(AZ_FLT_TINY, probs[a]);
+}
+
+// `cached_probs` (or null): az_prior_probs of these logits, worked out earlier.
 template <int AMAX>
 AZ_DEV void az_gumbel_pre(const az_search_desc& d, int A, const float (&logits)[AMAX],
-                          const int32_t (&vis)[AMAX], GumbelPre<AMAX>& g) {
-  az_softmax_fast<AMAX>(logits, A, g.probs);
+                          const int32_t (&vis)[AMAX], GumbelPre<AMAX>& g,
+                          const float* cached_probs = nullptr) {
+  if (cached_probs != nullptr) {
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) g.probs[a] = cached_probs[a];
+  } else {
+    az_prior_probs<AMAX>(logits, A, g.probs);
+  }
   int32_t sum_visits = 0, maxvisit = vis[0];
   g.sum_probs = 0.0f;
 AZ_UNROLL_A
@@ -626,7 +644,6 @@ AZ_UNROLL_A
     if (a < A) {
       sum_visits += vis[a];
       if (a > 0 && vis[a] > maxvisit) maxvisit = vis[a];
-      g.probs[a] = az_max_nan(AZ_FLT_TINY, g.probs[a]);
       g.sum_probs = g.sum_probs + (vis[a] > 0 ? g.probs[a] : 0.0f);
     }
   g.sum_visits = sum_visits;
@@ -724,6 +741,9 @@ AZ_DEV float az_from_next_lane_keep(float x) {
 // thread p % 32 of the lane in pass p / 32.  ev_logits [A] / ev_value [K] / reward / discount
 // are the recurrent_fn's outputs for this lane (any address space; read by every thread).
 // `pre` (or null): the rows of pass 0, loaded by az_wave_load ahead of the evaluation.
+// `node_probs` (or null; Gumbel rules): [S + 1][A] words of LDS per lane with az_prior_probs of
+// every node's prior logits, slot sim + 1 filled by the caller with those of simulation sim's
+// evaluation before that simulation's update (a fresh node IS node sim + 1).
 //
 // The backup's value chain  lv(p) = reward(p) + discount(p) * lv(p + 1)  runs as a fixed-point
 // iteration over the wave's lanes: every step, every thread recomputes its value from the one
@@ -737,7 +757,7 @@ template <int AMAX, int KMAX, bool NOISY, bool FAST_GUMBEL = false>
 AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active,
                            int h, int j, int sim, const WavePath& wp, const float* ev_logits,
                            const float* ev_value, float reward, float discount,
-                           const WaveRow<AMAX, KMAX>* pre = nullptr) {
+                           const WaveRow<AMAX, KMAX>* pre = nullptr, float* node_probs = nullptr) {
   const int A = l.A, K = l.K;
   const int dep = wp.dep;
   const RootCache rc = s.root_cache(c);
@@ -776,7 +796,9 @@ AZ_UNROLL_A
           if (leaf) f.logits[a] = ev_logits[a];
           if (!leaf && a == act) f.vis[a] = f.vis[a] + 1;
         }
-      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre);
+      // (slot sim + 1 of node_probs holds the values for this simulation's evaluation)
+      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre,
+                          node_probs != nullptr ? node_probs + (leaf ? sim + 1 : node) * A : nullptr);
       az_gumbel_pre_pin<AMAX>(A, gpre);
     }
     // the edge from this position's node to the next node of the path
@@ -862,6 +884,12 @@ AZ_UNROLL_K
           }
         l.par[node] = wl.parent;
         l.afp[node] = wl.action;
+        if (FAST_GUMBEL && node_probs != nullptr) {
+          // an existing node expanded again at the depth cap takes the new evaluation's values
+AZ_UNROLL_A
+          for (int a = 0; a < AZ_TRIP_A; ++a)
+            if (a < A) node_probs[node * A + a] = gpre.probs[a];
+        }
       } else {
         if (p == dep - 1) {
           // the edge parent -> evaluated node (search.py:235-241)
