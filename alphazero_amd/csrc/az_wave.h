@@ -581,6 +581,7 @@ struct GumbelPre {
   float ratio[AMAX];  // visits / (1 + sum of visits)
   float sum_probs, fsum, fsum1, scale;
   int32_t sum_visits;
+  int32_t considered_visit;  // the root rule's table entry for this visit count (seq_halving.py:36-70)
 };
 
 // IEEE 754-2019 maximum / minimum (one instruction each on gfx950).  Like jnp.maximum / minimum
@@ -592,6 +593,20 @@ AZ_DEV float az_min_nan(float a, float b) { return __builtin_elementwise_minimum
 // jax.nn.softmax as az_softmax, with the one-instruction maximum.
 template <int AMAX>
 AZ_DEV void az_softmax_fast(const float (&x)[AMAX], int A, float (&out)[AMAX]) {
+  if (AMAX == 2 && A == 2) {
+    // Two actions: the larger one's exponential is exp(m - m), i.e. 1 (or NaN when m is not
+    // finite: t below), so only the smaller one's is evaluated; 1 + e and e + 1 are the same sum.
+    const float m = az_max_nan(x[0], x[1]), lo = az_min_nan(x[0], x[1]);
+    const float t = m - m;               // +0, or NaN for an infinite or NaN maximum
+    const float e = az_expf(lo - m) + t;  // (e + 0 is e)
+    const float one = 1.0f + t;
+    const bool first = x[0] >= x[1];  // equal inputs: both exponentials are 1 either way
+    const float e0 = first ? one : e, e1 = first ? e : one;
+    const float s = e0 + e1;
+    out[0] = e0 / s;
+    out[1] = e1 / s;
+    return;
+  }
   float m = x[0];
 AZ_UNROLL_A
   for (int a = 1; a < AZ_TRIP_A; ++a)
@@ -628,7 +643,7 @@ AZ_UNROLL_A
 // `cached_probs` (or null): az_prior_probs of these logits, worked out earlier.
 template <int AMAX>
 AZ_DEV void az_gumbel_pre(const az_search_desc& d, int A, const float (&logits)[AMAX],
-                          const int32_t (&vis)[AMAX], GumbelPre<AMAX>& g,
+                          const int32_t (&vis)[AMAX], GumbelPre<AMAX>& g, const int32_t* table_row,
                           const float* cached_probs = nullptr) {
   if (cached_probs != nullptr) {
 AZ_UNROLL_A
@@ -647,6 +662,14 @@ AZ_UNROLL_A
       g.sum_probs = g.sum_probs + (vis[a] > 0 ? g.probs[a] : 0.0f);
     }
   g.sum_visits = sum_visits;
+  {
+    // requested here by every thread (only the root's is used) so that the read is not waited
+    // for inside the root's branch behind the backup; every index is inside the row
+    int32_t sim_index = sum_visits;
+    if (sim_index > d.S - 1) sim_index = d.S - 1;
+    if (sim_index < 0) sim_index = 0;
+    g.considered_visit = table_row[sim_index];
+  }
   g.fsum = (float)sum_visits;
   g.fsum1 = (float)(sum_visits + 1);
 AZ_UNROLL_A
@@ -667,6 +690,7 @@ AZ_UNROLL_A
     }
   g.sum_probs = az_pin(g.sum_probs);
   g.scale = az_pin(g.scale);
+  asm volatile("" : "+v"(g.considered_visit));
 }
 
 // q: mean over atoms of reward + discount * child value per action; raw: mean raw value.
@@ -712,9 +736,7 @@ AZ_UNROLL_A
     // root rule (action_selection.py:148-200, seq_halving.py:23-33): the number of considered
     // actions is fixed per search, so the table row is the cached one, and gumbel + (logits -
     // max logits) was added up once by az_wave_init
-    int32_t sim_index = g.sum_visits;
-    if (sim_index > d.S - 1) sim_index = d.S - 1;
-    const int32_t considered_visit = rc.table_row[sim_index];
+    const int32_t considered_visit = g.considered_visit;
     float score[AMAX];
 AZ_UNROLL_A
     for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -797,7 +819,7 @@ AZ_UNROLL_A
           if (!leaf && a == act) f.vis[a] = f.vis[a] + 1;
         }
       // (slot sim + 1 of node_probs holds the values for this simulation's evaluation)
-      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre,
+      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre, rc.table_row,
                           node_probs != nullptr ? node_probs + (leaf ? sim + 1 : node) * A : nullptr);
       az_gumbel_pre_pin<AMAX>(A, gpre);
     }
