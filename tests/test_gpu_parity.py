@@ -536,3 +536,61 @@ def test_scalar_value_layout(hip):
     assert np.array_equal(t.children_values.cpu().numpy(), ref["children_values"][..., 0])
     s = t.summary()
     assert s.value.shape == (8,) and s.qvalues.shape == (8, 3)
+
+
+# ---------------------------------------------------------------- second, independent checker
+NUMPY_CASES = [
+    dict(variant="gumbel", B=32, S=16, A=4, K=1),
+    dict(variant="gumbel", B=64, S=48, A=2, K=1),           # the headline shape's rule instantiation
+    dict(variant="gumbel", B=16, S=24, A=6, K=3, with_invalid=True),
+    dict(variant="gumbel", B=16, S=24, A=3, K=1, max_depth=3),
+    dict(variant="muzero", B=32, S=16, A=4, K=1),
+    dict(variant="muzero", B=16, S=24, A=3, K=2, with_invalid=True),
+    dict(variant="sampled", B=32, S=16, A=4, K=8),
+    dict(variant="sampled", B=16, S=24, A=3, K=1, with_invalid=True),
+]
+
+
+def _assert_close_to_numpy(out, ref, max_tie_lanes, rtol=1e-5, atol=1e-6):
+    """The NumPy checker shares no code with the library (NumPy's libm, BLAS products), so
+    selection scores may differ in the last bit and pick another action on a floating-point
+    near-tie: such lanes must stay rare, all others have identical integer arrays and float
+    arrays within the north star's 1e-5 relative."""
+    B = out["node_visits"].shape[0]
+    same = np.ones(B, bool)
+    for f in hip_int_fields:
+        same &= (out[f].reshape(B, -1) == ref[f].reshape(B, -1)).all(1)
+    assert int((~same).sum()) <= max_tie_lanes, f"{int((~same).sum())} of {B} lanes differ"
+    for f in hip_flt_fields + ("action_weights",):
+        np.testing.assert_allclose(out[f][same], ref[f].reshape(out[f].shape)[same], rtol=rtol, atol=atol,
+                                   err_msg=f)
+    assert np.array_equal(out["action"][same], ref["action"][same])
+
+
+hip_int_fields = ("node_visits", "parents", "action_from_parent", "children_index", "children_visits")
+hip_flt_fields = ("raw_values", "node_values", "children_prior_logits", "children_rewards",
+                  "children_discounts", "children_values")
+
+
+@pytest.mark.parametrize("kw", NUMPY_CASES, ids=_ids)
+def test_tree_kernel_vs_numpy_checker(hip, kw):
+    """The HIP search against oracle/mctx_numpy.py directly: unlike the plain-C checker it does
+    not include the library's numerics header, so exp / log / softmax come from NumPy."""
+    case = _case(kw, seed=23)
+    ref = runners.run_policy_numpy(case)
+    out = hip.run_policy_hip(case, "persistent")
+    _assert_close_to_numpy(out, ref, max_tie_lanes=max(1, case["B"] // 16))
+
+
+@pytest.mark.parametrize("env_id,variant", [("CartPole-v1", "gumbel"), ("MountainCar-v0", "muzero"),
+                                            ("Acrobot-v1", "sampled")])
+def test_fused_search_vs_numpy_checker(hip, env_id, variant):
+    """Environment step, networks (NumPy matrix products, libm sin / cos / exp) and tree of the
+    fused kernel against the NumPy checker; float32 summation order differs, hence 2e-4."""
+    case = runners.synthetic_case(variant, B=8, S=12, K=1, seed=3, env_id=env_id,
+                                  policy_hidden=(32, 32), value_hidden=(64, 64, 64), random_bias=True)
+    ref = runners.run_policy_numpy(case)
+    out = hip.run_policy_hip(case, "persistent")
+    _assert_close_to_numpy(out, ref, max_tie_lanes=1, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out["emb_state"], ref["emb_state"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(out["emb_time"], ref["emb_time"])
