@@ -89,6 +89,8 @@ def test_threefry_device(hip, oracle):
 INJECTED_CASES = [
     dict(variant="gumbel", B=64, S=32, A=2, K=1),
     dict(variant="gumbel", B=37, S=16, A=4, K=1),
+    # value spreads below the rescaling epsilon (the two-action rule's division path)
+    dict(variant="gumbel", B=64, S=32, A=2, K=1, qt_kwargs=dict(epsilon=0.3)),
     dict(variant="gumbel", B=16, S=24, A=6, K=3, with_invalid=True),
     dict(variant="gumbel", B=16, S=24, A=3, K=1, max_depth=3),
     dict(variant="gumbel", B=16, S=16, A=4, K=1, qt_kwargs=dict(use_mixed_value=False)),
@@ -235,6 +237,7 @@ FUSED_CASES = [
     ("CartPole-v1", "sampled", 20, 40, 16, {}),     # 16-atom value head
     ("MountainCar-v0", "gumbel", 16, 24, 16, {}),
     ("CartPole-v1", "gumbel", 16, 20, 1, dict(max_depth=3)),
+    ("CartPole-v1", "gumbel", 24, 24, 1, dict(qt_kwargs=dict(epsilon=0.3))),
 ]
 
 

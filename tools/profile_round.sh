@@ -7,7 +7,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary"
+BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
