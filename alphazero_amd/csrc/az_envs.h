@@ -216,20 +216,24 @@ AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut
   }
 }
 
+// `obs` has room for six values whatever the environment; those past its observation size are
+// scratch.  All six are written on one path: branches that end in stores to different elements
+// get their last stores merged into one store through a selected address, which this build's
+// compiler has been seen to leave undefined on one of the paths.
 AZ_DEV void az_env_obs(int env_id, const EnvState& st, float* obs) {
-  if (env_id == AZ_ENV_CARTPOLE) {
-    for (int i = 0; i < 4; ++i) obs[i] = st.s[i];
-  } else if (env_id == AZ_ENV_MOUNTAINCAR) {
-    obs[0] = st.s[0];
-    obs[1] = st.s[1];
-  } else {
-    obs[0] = az_cosf(st.s[0]);
-    obs[1] = az_sinf(st.s[0]);
-    obs[2] = az_cosf(st.s[1]);
-    obs[3] = az_sinf(st.s[1]);
-    obs[4] = st.s[2];
-    obs[5] = st.s[3];
+  float o[6] = {st.s[0], st.s[1], st.s[2], st.s[3], 0.0f, 0.0f};  // CartPole: the state; MountainCar: its first two
+  if (env_id == AZ_ENV_ACROBOT) {
+    const float c1 = az_cosf(st.s[0]), s1 = az_sinf(st.s[0]);
+    const float c2 = az_cosf(st.s[1]), s2 = az_sinf(st.s[1]);
+    o[0] = c1;
+    o[1] = s1;
+    o[2] = c2;
+    o[3] = s2;
+    o[4] = st.s[2];
+    o[5] = st.s[3];
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) obs[i] = o[i];
 }
 
 // reset_env of the three environments (cartpole.py:93-108, mountain_car.py:74-80,

@@ -26,6 +26,14 @@
 #else
 #define AZ_HD static inline
 #endif
+/* AZ_COMPUTED_HERE(x): on the GPU, x is evaluated at this point whatever selects
+ * follow (the optimiser otherwise turns "special ? constant : x" back into a
+ * branch around the evaluation of x); no effect on the value. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AZ_COMPUTED_HERE(x) asm volatile("" : "+v"(x))
+#else
+#define AZ_COMPUTED_HERE(x) ((void)0)
+#endif
 
 #define AZ_INF (__builtin_inff())
 #define AZ_NAN (__builtin_nanf(""))
@@ -135,25 +143,23 @@ AZ_HD float az_logf(float x) {
 }
 
 /* Shared octant reduction for sin / cos: returns the reduced argument in
- * [-pi/4, pi/4] and the octant index j (even, 0..6).  |x| >= 2^30 has no
- * significant fraction left in binary32 and is mapped to 0 * x. */
+ * [-pi/4, pi/4] and the octant index j (even, 0..6) of a finite ax in
+ * [0, 2^30).  Like az_expf, sin and cos are written without branches or early
+ * returns (selects only; special inputs run on the stand-in 0 and are replaced
+ * at the end): the environment steps evaluate several of them side by side,
+ * and only straight-line code lets their instructions interleave. */
 AZ_HD float az_trig_reduce_(float ax, int* j_out) {
   int j = (int)(ax * 1.27323949337005615234375f); /* 4/pi */
-  float y = (float)j;
-  if (j & 1) {
-    j += 1;
-    y += 1.0f;
-  }
+  const float y0 = (float)j;
+  const int odd = j & 1;
+  const float y = odd ? y0 + 1.0f : y0;
+  j += odd;
   *j_out = j & 7;
-  float r;
-  if (ax > 8192.0f) {
-    r = az_fmaf(y, -0.785398185253143310546875f, ax);
-  } else {
-    r = az_fmaf(y, -0.78515625f, ax);
-    r = az_fmaf(y, -2.4187564849853515625e-4f, r);
-    r = az_fmaf(y, -3.77489497744594108e-8f, r);
-  }
-  return r;
+  const float r_far = az_fmaf(y, -0.785398185253143310546875f, ax);
+  float r = az_fmaf(y, -0.78515625f, ax);
+  r = az_fmaf(y, -2.4187564849853515625e-4f, r);
+  r = az_fmaf(y, -3.77489497744594108e-8f, r);
+  return ax > 8192.0f ? r_far : r;
 }
 AZ_HD float az_sin_poly_(float r) {
   float z = r * r;
@@ -171,34 +177,43 @@ AZ_HD float az_cos_poly_(float r) {
   y = az_fmaf(-0.5f, z, y);
   return y + 1.0f;
 }
+/* |x| >= 2^30 has no significant fraction left in binary32: sin gives 0 * x
+ * (NaN for an infinity), cos 1 (NaN for an infinity).  NaN returns itself. */
 AZ_HD float az_sinf(float x) {
-  if (x != x) return x;
-  float ax = x < 0.0f ? -x : x;
-  if (!(ax < 1073741824.0f)) return 0.0f * x;
+  const int is_nan = x != x;
+  const float ax0 = x < 0.0f ? -x : x;
+  const int far = !(ax0 < 1073741824.0f); /* also true for NaN */
+  const float ax = far ? 0.0f : ax0;
   int j;
-  float r = az_trig_reduce_(ax, &j);
+  const float r = az_trig_reduce_(ax, &j);
   int neg = x < 0.0f;
-  if (j > 3) {
-    neg = !neg;
-    j -= 4;
-  }
-  float y = (j == 2) ? az_cos_poly_(r) : az_sin_poly_(r);
-  return neg ? -y : y;
+  const int upper = j > 3;
+  neg = upper ? !neg : neg;
+  j = upper ? j - 4 : j;
+  const float ys = az_sin_poly_(r), yc = az_cos_poly_(r);
+  float y = (j == 2) ? yc : ys;
+  y = neg ? -y : y;
+  AZ_COMPUTED_HERE(y);
+  y = far ? 0.0f * x : y;
+  return is_nan ? x : y;
 }
 AZ_HD float az_cosf(float x) {
-  if (x != x) return x;
-  float ax = x < 0.0f ? -x : x;
-  if (!(ax < 1073741824.0f)) return 0.0f * x + (ax == AZ_INF ? 0.0f : 1.0f);
+  const int is_nan = x != x;
+  const float ax0 = x < 0.0f ? -x : x;
+  const int far = !(ax0 < 1073741824.0f); /* also true for NaN */
+  const float ax = far ? 0.0f : ax0;
   int j;
-  float r = az_trig_reduce_(ax, &j);
-  int neg = 0;
-  if (j > 3) {
-    neg = 1;
-    j -= 4;
-  }
-  if (j > 1) neg = !neg;
-  float y = (j == 2) ? az_sin_poly_(r) : az_cos_poly_(r);
-  return neg ? -y : y;
+  const float r = az_trig_reduce_(ax, &j);
+  const int upper = j > 3;
+  int neg = upper;
+  j = upper ? j - 4 : j;
+  neg = (j > 1) ? !neg : neg;
+  const float ys = az_sin_poly_(r), yc = az_cos_poly_(r);
+  float y = (j == 2) ? ys : yc;
+  y = neg ? -y : y;
+  AZ_COMPUTED_HERE(y);
+  y = far ? 0.0f * x + (ax0 == AZ_INF ? 0.0f : 1.0f) : y;
+  return is_nan ? x : y;
 }
 
 /* logistic(x) = 1 / (1 + exp(t)) with t = -x clamped to [-64, 64];  swish(x) = x * logistic(x).
