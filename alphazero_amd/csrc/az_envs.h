@@ -82,19 +82,55 @@ AZ_DEV void az_mountaincar_step(EnvState& st, int action, EnvOut& o) {
   o.obs[1] = velocity;
 }
 
+// The value thread Q of the caller's group of four (threads 4k ... 4k + 3 of the wave) holds: one
+// DPP move.  All four threads must be active.
+template <int Q>
+AZ_DEV float az_quad_value(float x) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), Q * 0x55, 0xf, 0xf, true));
+}
+
+// Four sines / cosines at once.  QUAD: the caller is a group of four threads (4k ... 4k + 3 of the
+// wave, all active) that hold the SAME arguments and all want all four results; thread q
+// evaluates the q-th function (a sine and a cosine are one instruction stream, az_trig_) and the
+// results are exchanged, so the group pays for one evaluation instead of four.  Each value is
+// the same az_sinf / az_cosf of the same argument either way.
+template <bool QUAD>
+AZ_DEV void az_trig4(float x0, bool cos0, float x1, bool cos1, float x2, bool cos2, float x3, bool cos3,
+                     float& y0, float& y1, float& y2, float& y3) {
+  if (QUAD) {
+    const int q = threadIdx.x & 3;
+    const float x = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+    const bool c = q == 0 ? cos0 : (q == 1 ? cos1 : (q == 2 ? cos2 : cos3));
+    const float y = az_trig_(x, c);
+    y0 = az_quad_value<0>(y);
+    y1 = az_quad_value<1>(y);
+    y2 = az_quad_value<2>(y);
+    y3 = az_quad_value<3>(y);
+  } else {
+    y0 = az_trig_(x0, cos0);
+    y1 = az_trig_(x1, cos1);
+    y2 = az_trig_(x2, cos2);
+    y3 = az_trig_(x3, cos3);
+  }
+}
+
 // acrobot.py:202-233
+template <bool QUAD = false>
 AZ_DEV void az_acrobot_dsdt(const float (&s)[5], float (&out)[5]) {
   const float m1 = 1.0f, m2 = 1.0f, l1 = 1.0f, lc1 = 0.5f, lc2 = 0.5f, I1 = 1.0f, I2 = 1.0f,
               g = 9.8f, half_pi = 1.5707963267948966f;
   float a = s[4];
   float theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
-  float c2 = az_cosf(theta2), s2 = az_sinf(theta2);
+  float c2, s2, c12, c1;  // cos(theta2), sin(theta2), cos(theta1 + theta2 - pi/2), cos(theta1 - pi/2)
+  az_trig4<QUAD>(theta2, true, theta2, false, (theta1 + theta2) - half_pi, true, theta1 - half_pi, true,
+                 c2, s2, c12, c1);
   float d1 = ((m1 * (lc1 * lc1) + m2 * (((l1 * l1) + (lc2 * lc2)) + (((2.0f * l1) * lc2) * c2))) + I1) + I2;
   float d2 = m2 * ((lc2 * lc2) + (l1 * lc2) * c2) + I2;
-  float phi2 = ((m2 * lc2) * g) * az_cosf((theta1 + theta2) - half_pi);
+  float phi2 = ((m2 * lc2) * g) * c12;
   float phi1 = ((((((-m2) * l1) * lc2) * (dtheta2 * dtheta2)) * s2 -
                  (((((2.0f * m2) * l1) * lc2) * dtheta2) * dtheta1) * s2) +
-                ((m1 * lc1 + m2 * l1) * g) * az_cosf(theta1 - half_pi)) +
+                ((m1 * lc1 + m2 * l1) * g) * c1) +
                phi2;
   float ddtheta2 = (((a + (d2 / d1) * phi1) - (((m2 * l1) * lc2) * (dtheta1 * dtheta1)) * s2) - phi2) /
                    ((m2 * (lc2 * lc2) + I2) - (d2 * d2) / d1);
@@ -117,6 +153,9 @@ AZ_DEV float az_acrobot_wrap(float x, float m, float M) {
 }
 
 // acrobot.py:52-106, 137-147, 250-258
+// QUAD: called by a group of four threads with the same state and action (see az_trig4); all
+// four end up with the same results.
+template <bool QUAD = false>
 AZ_DEV void az_acrobot_step(EnvState& st, int action, EnvOut& o) {
   const float dt = 0.2f, pi = 3.141592653589793f, max_vel_1 = 12.566370614359172f,
               max_vel_2 = 28.274333882308138f;
@@ -125,16 +164,16 @@ AZ_DEV void az_acrobot_step(EnvState& st, int action, EnvOut& o) {
   float y0[5] = {st.s[0], st.s[1], st.s[2], st.s[3], torque};
   float k1[5], k2[5], k3[5], k4[5], tmp[5];
   float dt2 = dt / 2.0f;
-  az_acrobot_dsdt(y0, k1);
+  az_acrobot_dsdt<QUAD>(y0, k1);
 #pragma unroll
   for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k1[i];
-  az_acrobot_dsdt(tmp, k2);
+  az_acrobot_dsdt<QUAD>(tmp, k2);
 #pragma unroll
   for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt2 * k2[i];
-  az_acrobot_dsdt(tmp, k3);
+  az_acrobot_dsdt<QUAD>(tmp, k3);
 #pragma unroll
   for (int i = 0; i < 5; ++i) tmp[i] = y0[i] + dt * k3[i];
-  az_acrobot_dsdt(tmp, k4);
+  az_acrobot_dsdt<QUAD>(tmp, k4);
   float ns[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -143,7 +182,8 @@ AZ_DEV void az_acrobot_step(EnvState& st, int action, EnvOut& o) {
   float ja2 = az_acrobot_wrap(ns[1], -pi, pi);
   float v1 = az_minf(az_maxf(ns[2], -max_vel_1), max_vel_1);
   float v2 = az_minf(az_maxf(ns[3], -max_vel_2), max_vel_2);
-  float cos1 = az_cosf(ja1);
+  float cos1, sin1, cos2, sin2;
+  az_trig4<QUAD>(ja1, true, ja1, false, ja2, true, ja2, false, cos1, sin1, cos2, sin2);
   int done_angle = ((-cos1) - az_cosf(ja2 + ja1)) > 1.0f;
   o.reward = -1.0f * (float)(1 - done_angle);
   st.s[0] = ja1;
@@ -154,9 +194,9 @@ AZ_DEV void az_acrobot_step(EnvState& st, int action, EnvOut& o) {
   o.terminated = done_angle ? 1.0f : 0.0f;
   o.truncated = st.time >= 5000 ? 1.0f : 0.0f;
   o.obs[0] = cos1;
-  o.obs[1] = az_sinf(ja1);
-  o.obs[2] = az_cosf(ja2);
-  o.obs[3] = az_sinf(ja2);
+  o.obs[1] = sin1;
+  o.obs[2] = cos2;
+  o.obs[3] = sin2;
   o.obs[4] = v1;
   o.obs[5] = v2;
 }
@@ -198,7 +238,8 @@ AZ_DEV void az_env_step_rt(int env_id, EnvState& st, int action, EnvOut& o) {
 
 // The environments an action count admits (az_env_num_actions): with A known at compile time
 // the other environments' code is not generated.
-template <int A_EXACT>
+// QUAD: the caller is a group of four threads with the same state and action (az_trig4).
+template <int A_EXACT, bool QUAD = false>
 AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut& o) {
   if (A_EXACT == 2) {
     az_cartpole_step(st, action, o);
@@ -208,7 +249,7 @@ AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut
       az_mountaincar_step(st, action, t);
       az_env_out_copy(o, t);
     } else {
-      az_acrobot_step(st, action, t);
+      az_acrobot_step<QUAD>(st, action, t);
       az_env_out_copy(o, t);
     }
   } else {

@@ -208,10 +208,10 @@ extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float*
 
 // alphazero.py:317-339 on one lane: environment step, reward and discount.
 // A_EXACT: the model's action count when it is known at compile time, else 0.
-template <int A_EXACT = 0>
+template <int A_EXACT = 0, bool QUAD = false>
 AZ_DEV void az_model_env_step(const ModelDev& md, EnvState& st, int action, EnvOut& o, float& reward,
                               float& discount) {
-  az_env_step_for_actions<A_EXACT>(md.env_id, st, action, o);
+  az_env_step_for_actions<A_EXACT, QUAD>(md.env_id, st, action, o);
   reward = o.reward;
   discount = md.gamma * (o.truncated != 0.0f ? 1.0f : 1.0f - o.terminated);
 }
@@ -437,8 +437,13 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         wp = az_wave_chase_lean(ws, h, j, sim, d.max_depth, active);
       AZ_SIM_STAMP(1);
       az_forward_prime_slots<6, 11>(first_unit, lane, regs);
-      if (leader) {
-        __hip_atomic_fetch_add(&ws.hdr[6], wp.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // (one LDS add, nothing returned)
+      // Three actions (MountainCar, Acrobot): the lane's first FOUR threads step the environment
+      // together -- Acrobot's step is 21 sines and cosines, four at a time with four threads
+      // (az_trig4) -- and the first of them alone writes.
+      constexpr bool kQuadEnv = EXACT && AMAX == 3;
+      if (kQuadEnv ? (active && j < 4) : leader) {
+        if (leader)
+          __hip_atomic_fetch_add(&ws.hdr[6], wp.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // (one LDS add, nothing returned)
         const WaveLeaf wl = az_wave_leaf(ws, wp.dep, sim);
         EnvState st;
         float* const emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
@@ -457,22 +462,24 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         EnvOut o{};
         float reward, discount;
         AZ_SIM_STAMP(6);
-        az_model_env_step<EXACT ? AMAX : 0>(md, st, wl.action, o, reward, discount);
+        az_model_env_step<EXACT ? AMAX : 0, kQuadEnv>(md, st, wl.action, o, reward, discount);
         AZ_SIM_STAMP(7);
-        if (emb) {
+        if (leader) {
+          if (emb) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) emb[wl.node * 5 + i] = st.s[i];
-          emb[wl.node * 5 + 4] = az_u2f((uint32_t)st.time);
-        }
-        ws.hdr[4] = (int32_t)az_f2u(reward);
-        ws.hdr[5] = (int32_t)az_f2u(discount);
-        az_store_obs<true, (EXACT && AMAX == 2) ? 4 : 0>(md, s, ln, o.obs);  // two actions: CartPole
-        // the caller's copy of the new node's environment state (with the states in LDS it is
-        // written once, after the last simulation)
-        if (!emb) {
+            for (int i = 0; i < 4; ++i) emb[wl.node * 5 + i] = st.s[i];
+            emb[wl.node * 5 + 4] = az_u2f((uint32_t)st.time);
+          }
+          ws.hdr[4] = (int32_t)az_f2u(reward);
+          ws.hdr[5] = (int32_t)az_f2u(discount);
+          az_store_obs<true, (EXACT && AMAX == 2) ? 4 : 0>(md, s, ln, o.obs);  // two actions: CartPole
+          // the caller's copy of the new node's environment state (with the states in LDS it is
+          // written once, after the last simulation)
+          if (!emb) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
-          l.et[wl.node] = st.time;
+            for (int i = 0; i < 4; ++i) l.es[(size_t)wl.node * 4 + i] = st.s[i];
+            l.et[wl.node] = st.time;
+          }
         }
         AZ_SIM_STAMP(8);
       }

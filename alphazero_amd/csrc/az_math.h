@@ -102,27 +102,23 @@ AZ_HD float az_expf(float x) {
 }
 
 /* log(x): frexp by bit manipulation (subnormals pre-scaled by 2^23), the
- * Cephes degree-8 polynomial on m - 1 with m in [sqrt(1/2), sqrt(2)). */
+ * Cephes degree-8 polynomial on m - 1 with m in [sqrt(1/2), sqrt(2)).
+ * Selects only, like az_expf: NaN, negative, zero and infinite inputs are
+ * evaluated on the stand-in 1 and replaced at the end. */
 AZ_HD float az_logf(float x) {
-  if (x != x) return x;
-  if (x < 0.0f) return AZ_NAN;
-  if (x == 0.0f) return -AZ_INF;
-  if (x == AZ_INF) return x;
-  int e = 0;
-  uint32_t ux = az_f2u(x);
-  if (ux < 0x00800000u) {
-    x = x * 8388608.0f;
-    e = -23;
-    ux = az_f2u(x);
-  }
-  e += (int)(ux >> 23) - 126;
-  float m = az_u2f((ux & 0x007fffffu) | 0x3f000000u);
-  if (m < 0.707106769084930419921875f) {
-    e -= 1;
-    m = (m + m) - 1.0f;
-  } else {
-    m = m - 1.0f;
-  }
+  const int is_nan = x != x;
+  const int negative = x < 0.0f;
+  const int zero = x == 0.0f;
+  const int infinite = x == AZ_INF;
+  const float xs = (is_nan | negative | zero | infinite) ? 1.0f : x;
+  const uint32_t ux0 = az_f2u(xs);
+  const int subnormal = ux0 < 0x00800000u;
+  const uint32_t ux = subnormal ? az_f2u(xs * 8388608.0f) : ux0;
+  int e = (subnormal ? -23 : 0) + ((int)(ux >> 23) - 126);
+  const float m0 = az_u2f((ux & 0x007fffffu) | 0x3f000000u);
+  const int low = m0 < 0.707106769084930419921875f;
+  e = low ? e - 1 : e;
+  const float m = low ? (m0 + m0) - 1.0f : m0 - 1.0f;
   float z = m * m;
   float y = 7.0376836292e-2f;
   y = az_fmaf(y, m, -1.1514610310e-1f);
@@ -139,7 +135,11 @@ AZ_HD float az_logf(float x) {
   y = az_fmaf(-0.5f, z, y);
   float res = m + y;
   res = az_fmaf(fe, 0.693359375f, res);
-  return res;
+  AZ_COMPUTED_HERE(res);
+  res = infinite ? x : res;
+  res = zero ? -AZ_INF : res;
+  res = negative ? AZ_NAN : res;
+  return is_nan ? x : res;
 }
 
 /* Shared octant reduction for sin / cos: returns the reduced argument in
@@ -177,44 +177,35 @@ AZ_HD float az_cos_poly_(float r) {
   y = az_fmaf(-0.5f, z, y);
   return y + 1.0f;
 }
-/* |x| >= 2^30 has no significant fraction left in binary32: sin gives 0 * x
- * (NaN for an infinity), cos 1 (NaN for an infinity).  NaN returns itself. */
-AZ_HD float az_sinf(float x) {
+/* sin (want_cos == 0) or cos of x; one body for both so that a group of GPU
+ * threads can evaluate a mix of sines and cosines in one pass (with a constant
+ * flag it folds to the plain function).  |x| >= 2^30 has no significant
+ * fraction left in binary32: sin gives 0 * x (NaN for an infinity), cos 1 (NaN
+ * for an infinity).  NaN returns itself. */
+AZ_HD float az_trig_(float x, int want_cos) {
   const int is_nan = x != x;
   const float ax0 = x < 0.0f ? -x : x;
   const int far = !(ax0 < 1073741824.0f); /* also true for NaN */
   const float ax = far ? 0.0f : ax0;
   int j;
   const float r = az_trig_reduce_(ax, &j);
-  int neg = x < 0.0f;
+  int neg = want_cos ? 0 : (x < 0.0f);
   const int upper = j > 3;
   neg = upper ? !neg : neg;
   j = upper ? j - 4 : j;
+  neg = (want_cos && j > 1) ? !neg : neg;
   const float ys = az_sin_poly_(r), yc = az_cos_poly_(r);
-  float y = (j == 2) ? yc : ys;
+  const int cos_poly = want_cos ? (j != 2) : (j == 2);
+  float y = cos_poly ? yc : ys;
   y = neg ? -y : y;
   AZ_COMPUTED_HERE(y);
-  y = far ? 0.0f * x : y;
+  const float far_sin = 0.0f * x;
+  const float far_cos = 0.0f * x + (ax0 == AZ_INF ? 0.0f : 1.0f);
+  y = far ? (want_cos ? far_cos : far_sin) : y;
   return is_nan ? x : y;
 }
-AZ_HD float az_cosf(float x) {
-  const int is_nan = x != x;
-  const float ax0 = x < 0.0f ? -x : x;
-  const int far = !(ax0 < 1073741824.0f); /* also true for NaN */
-  const float ax = far ? 0.0f : ax0;
-  int j;
-  const float r = az_trig_reduce_(ax, &j);
-  const int upper = j > 3;
-  int neg = upper;
-  j = upper ? j - 4 : j;
-  neg = (j > 1) ? !neg : neg;
-  const float ys = az_sin_poly_(r), yc = az_cos_poly_(r);
-  float y = (j == 2) ? ys : yc;
-  y = neg ? -y : y;
-  AZ_COMPUTED_HERE(y);
-  y = far ? 0.0f * x + (ax0 == AZ_INF ? 0.0f : 1.0f) : y;
-  return is_nan ? x : y;
-}
+AZ_HD float az_sinf(float x) { return az_trig_(x, 0); }
+AZ_HD float az_cosf(float x) { return az_trig_(x, 1); }
 
 /* logistic(x) = 1 / (1 + exp(t)) with t = -x clamped to [-64, 64];  swish(x) = x * logistic(x).
  * The clamp is part of the specification: it moves the result by less than 2e-28 (logistic is
