@@ -404,6 +404,25 @@ def test_largest_configuration_full_size_properties(hip):
         assert np.array_equal(out[f][:64], ref[f].reshape(out[f][:64].shape)), f
 
 
+@pytest.mark.parametrize("env_id,variant", [("Acrobot-v1", "sampled"), ("MountainCar-v0", "gumbel"),
+                                            ("Acrobot-v1", "gumbel")])
+def test_three_action_environments_full_size_properties(hip, env_id, variant):
+    """The 8192-lane configuration of the three-action environments (the reference trainer's
+    default environment and policy among them) at full size: structural invariants on every lane
+    and bit equality of the first 64 lanes -- trees, environment states, actions, weights -- with
+    the CPU checker."""
+    B, S = 8192, 64
+    case = runners.synthetic_case(variant, B=B, S=S, K=1, seed=37, env_id=env_id, random_bias=True)
+    out = hip.run_policy_hip(case, "persistent")
+    check_invariants(out, S)
+    np.testing.assert_allclose(out["action_weights"].sum(-1), 1.0, rtol=1e-6)
+    head = {k: (v[:64] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in case.items()}
+    head["B"] = 64
+    ref = runners.run_policy_c(head)
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS + ("emb_state", "emb_time", "action", "action_weights"):
+        assert np.array_equal(out[f][:64], ref[f].reshape(out[f][:64].shape)), f
+
+
 # ---------------------------------------------------------------- device RNG paths
 def test_default_rng_paths_vs_oracle(hip, oracle):
     """Without injected noise the device threefry streams equal the C checker's."""
