@@ -102,23 +102,27 @@ AZ_HD float az_expf(float x) {
 }
 
 /* log(x): frexp by bit manipulation (subnormals pre-scaled by 2^23), the
- * Cephes degree-8 polynomial on m - 1 with m in [sqrt(1/2), sqrt(2)).
- * Selects only, like az_expf: NaN, negative, zero and infinite inputs are
- * evaluated on the stand-in 1 and replaced at the end. */
+ * Cephes degree-8 polynomial on m - 1 with m in [sqrt(1/2), sqrt(2)). */
 AZ_HD float az_logf(float x) {
-  const int is_nan = x != x;
-  const int negative = x < 0.0f;
-  const int zero = x == 0.0f;
-  const int infinite = x == AZ_INF;
-  const float xs = (is_nan | negative | zero | infinite) ? 1.0f : x;
-  const uint32_t ux0 = az_f2u(xs);
-  const int subnormal = ux0 < 0x00800000u;
-  const uint32_t ux = subnormal ? az_f2u(xs * 8388608.0f) : ux0;
-  int e = (subnormal ? -23 : 0) + ((int)(ux >> 23) - 126);
-  const float m0 = az_u2f((ux & 0x007fffffu) | 0x3f000000u);
-  const int low = m0 < 0.707106769084930419921875f;
-  e = low ? e - 1 : e;
-  const float m = low ? (m0 + m0) - 1.0f : m0 - 1.0f;
+  if (x != x) return x;
+  if (x < 0.0f) return AZ_NAN;
+  if (x == 0.0f) return -AZ_INF;
+  if (x == AZ_INF) return x;
+  int e = 0;
+  uint32_t ux = az_f2u(x);
+  if (ux < 0x00800000u) {
+    x = x * 8388608.0f;
+    e = -23;
+    ux = az_f2u(x);
+  }
+  e += (int)(ux >> 23) - 126;
+  float m = az_u2f((ux & 0x007fffffu) | 0x3f000000u);
+  if (m < 0.707106769084930419921875f) {
+    e -= 1;
+    m = (m + m) - 1.0f;
+  } else {
+    m = m - 1.0f;
+  }
   float z = m * m;
   float y = 7.0376836292e-2f;
   y = az_fmaf(y, m, -1.1514610310e-1f);
@@ -135,31 +139,29 @@ AZ_HD float az_logf(float x) {
   y = az_fmaf(-0.5f, z, y);
   float res = m + y;
   res = az_fmaf(fe, 0.693359375f, res);
-  AZ_COMPUTED_HERE(res);
-  res = infinite ? x : res;
-  res = zero ? -AZ_INF : res;
-  res = negative ? AZ_NAN : res;
-  return is_nan ? x : res;
+  return res;
 }
 
 /* Shared octant reduction for sin / cos: returns the reduced argument in
- * [-pi/4, pi/4] and the octant index j (even, 0..6) of a finite ax in
- * [0, 2^30).  Like az_expf, sin and cos are written without branches or early
- * returns (selects only; special inputs run on the stand-in 0 and are replaced
- * at the end): the environment steps evaluate several of them side by side,
- * and only straight-line code lets their instructions interleave. */
+ * [-pi/4, pi/4] and the octant index j (even, 0..6).  |x| >= 2^30 has no
+ * significant fraction left in binary32 and is mapped to 0 * x. */
 AZ_HD float az_trig_reduce_(float ax, int* j_out) {
   int j = (int)(ax * 1.27323949337005615234375f); /* 4/pi */
-  const float y0 = (float)j;
-  const int odd = j & 1;
-  const float y = odd ? y0 + 1.0f : y0;
-  j += odd;
+  float y = (float)j;
+  if (j & 1) {
+    j += 1;
+    y += 1.0f;
+  }
   *j_out = j & 7;
-  const float r_far = az_fmaf(y, -0.785398185253143310546875f, ax);
-  float r = az_fmaf(y, -0.78515625f, ax);
-  r = az_fmaf(y, -2.4187564849853515625e-4f, r);
-  r = az_fmaf(y, -3.77489497744594108e-8f, r);
-  return ax > 8192.0f ? r_far : r;
+  float r;
+  if (ax > 8192.0f) {
+    r = az_fmaf(y, -0.785398185253143310546875f, ax);
+  } else {
+    r = az_fmaf(y, -0.78515625f, ax);
+    r = az_fmaf(y, -2.4187564849853515625e-4f, r);
+    r = az_fmaf(y, -3.77489497744594108e-8f, r);
+  }
+  return r;
 }
 AZ_HD float az_sin_poly_(float r) {
   float z = r * r;
@@ -177,6 +179,57 @@ AZ_HD float az_cos_poly_(float r) {
   y = az_fmaf(-0.5f, z, y);
   return y + 1.0f;
 }
+AZ_HD float az_sinf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  if (!(ax < 1073741824.0f)) return 0.0f * x;
+  int j;
+  float r = az_trig_reduce_(ax, &j);
+  int neg = x < 0.0f;
+  if (j > 3) {
+    neg = !neg;
+    j -= 4;
+  }
+  float y = (j == 2) ? az_cos_poly_(r) : az_sin_poly_(r);
+  return neg ? -y : y;
+}
+AZ_HD float az_cosf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  if (!(ax < 1073741824.0f)) return 0.0f * x + (ax == AZ_INF ? 0.0f : 1.0f);
+  int j;
+  float r = az_trig_reduce_(ax, &j);
+  int neg = 0;
+  if (j > 3) {
+    neg = 1;
+    j -= 4;
+  }
+  if (j > 1) neg = !neg;
+  float y = (j == 2) ? az_sin_poly_(r) : az_cos_poly_(r);
+  return neg ? -y : y;
+}
+
+/* The same two functions in ONE body without branches or early returns (selects
+ * only; special inputs run on the stand-in 0 and are replaced at the end, as in
+ * az_expf): az_trig_(x, 0) == az_sinf(x) and az_trig_(x, 1) == az_cosf(x) bit for
+ * bit, NaN payloads included (compared on every 7th binary32 pattern).  For
+ * callers that evaluate several sines / cosines side by side -- straight-line
+ * code lets their instructions interleave, and a group of GPU threads can
+ * evaluate a mix of both in one pass.  Not a replacement for the forms above: in
+ * register-bound kernels their branches keep fewer values live. */
+AZ_HD float az_trig_reduce_sel_(float ax, int* j_out) {
+  int j = (int)(ax * 1.27323949337005615234375f); /* 4/pi */
+  const float y0 = (float)j;
+  const int odd = j & 1;
+  const float y = odd ? y0 + 1.0f : y0;
+  j += odd;
+  *j_out = j & 7;
+  const float r_far = az_fmaf(y, -0.785398185253143310546875f, ax);
+  float r = az_fmaf(y, -0.78515625f, ax);
+  r = az_fmaf(y, -2.4187564849853515625e-4f, r);
+  r = az_fmaf(y, -3.77489497744594108e-8f, r);
+  return ax > 8192.0f ? r_far : r;
+}
 /* sin (want_cos == 0) or cos of x; one body for both so that a group of GPU
  * threads can evaluate a mix of sines and cosines in one pass (with a constant
  * flag it folds to the plain function).  |x| >= 2^30 has no significant
@@ -188,7 +241,7 @@ AZ_HD float az_trig_(float x, int want_cos) {
   const int far = !(ax0 < 1073741824.0f); /* also true for NaN */
   const float ax = far ? 0.0f : ax0;
   int j;
-  const float r = az_trig_reduce_(ax, &j);
+  const float r = az_trig_reduce_sel_(ax, &j);
   int neg = want_cos ? 0 : (x < 0.0f);
   const int upper = j > 3;
   neg = upper ? !neg : neg;
@@ -204,8 +257,6 @@ AZ_HD float az_trig_(float x, int want_cos) {
   y = far ? (want_cos ? far_cos : far_sin) : y;
   return is_nan ? x : y;
 }
-AZ_HD float az_sinf(float x) { return az_trig_(x, 0); }
-AZ_HD float az_cosf(float x) { return az_trig_(x, 1); }
 
 /* logistic(x) = 1 / (1 + exp(t)) with t = -x clamped to [-64, 64];  swish(x) = x * logistic(x).
  * The clamp is part of the specification: it moves the result by less than 2e-28 (logistic is
