@@ -547,6 +547,8 @@ __global__ void k_math_apply(int fn, int n, const float* __restrict__ x, float* 
     case 5: r = az_sqrtf(v); break;
     case 6: r = 1.0f / v; break;
     case 7: r = az_gumbel_from_bits(az_f2u(v)); break;
+    case 9: r = az_trig_(v, 0); break;   // the select-only sine ...
+    case 10: r = az_trig_(v, 1); break;  // ... and cosine (the Acrobot step's form)
     default: r = v;
   }
   y[i] = r;

@@ -239,7 +239,8 @@ int az_real_env_step(int32_t env_id, int32_t B, int32_t episode_length, float* s
 
 /* Device evaluation of the numerics specification (exp, log, sin, cos, swish, sqrt,
  * reciprocal, gumbel-from-bits: fn = 0..7; fn = 8: swish in the packed form the dense
- * layers' epilogue uses) and of the threefry block, used to check
+ * layers' epilogue uses; fn = 9, 10: sine and cosine in the select-only form the Acrobot step
+ * uses) and of the threefry block, used to check
  * that host and device produce the same bits.  No counterpart in the reference. */
 int az_math_apply(int32_t fn, int32_t n, const float* x, float* y, void* stream);
 int az_threefry(int32_t n, const uint32_t* key, const uint32_t* ctr, uint32_t* out, void* stream);

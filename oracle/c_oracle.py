@@ -317,7 +317,7 @@ def actor_post(cfg, tree, action_weights, sampled_action, deterministic, prior_l
 
 
 _MATH_FN = {"exp": 0, "log": 1, "sin": 2, "cos": 3, "swish": 4, "sqrt": 5, "rcp": 6,
-            "gumbel_from_bits": 7}
+            "gumbel_from_bits": 7, "sin_select": 9, "cos_select": 10}
 
 
 def math_apply(fn, x):

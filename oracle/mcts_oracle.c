@@ -1043,6 +1043,8 @@ void oz_math_apply(int fn, int n, const float* x, float* y) {
       case 5: y[i] = az_sqrtf(v); break;
       case 6: y[i] = 1.0f / v; break;
       case 7: y[i] = az_gumbel_from_bits(az_f2u(v)); break;
+      case 9: y[i] = az_trig_(v, 0); break;  /* select-only forms of sin / cos */
+      case 10: y[i] = az_trig_(v, 1); break;
       default: y[i] = v;
     }
   }

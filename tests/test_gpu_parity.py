@@ -28,11 +28,15 @@ def hip():
 @pytest.mark.parametrize("fn,lo,hi", [("exp", -110.0, 90.0), ("log", 0.0, 1e30), ("sin", -40.0, 40.0),
                                       ("cos", -40.0, 40.0), ("swish", -100.0, 100.0),
                                       ("sqrt", 0.0, 1e30), ("rcp", -1e3, 1e3),
-                                      ("swish_packed", -100.0, 100.0), ("swish_packed", -8.0, 8.0)])
+                                      ("swish_packed", -100.0, 100.0), ("swish_packed", -8.0, 8.0),
+                                      ("sin_select", -40.0, 40.0), ("cos_select", -40.0, 40.0),
+                                      ("sin_select", -3e9, 3e9), ("cos_select", -3e9, 3e9)])
 def test_numerics_spec_host_device_bits(hip, oracle, fn, lo, hi):
     """Every elementary function gives the same bits on the host and on gfx950.
     swish_packed is swish the way the dense layers' epilogue issues it (packed pairs, a
-    shorter form for |x| <= 64): checked against the same host function."""
+    shorter form for |x| <= 64): checked against the same host function.  sin_select /
+    cos_select: the select-only form the Acrobot step evaluates, on the device, against the
+    early-return form on the host."""
     from alphazero_amd import _native as nat
     rng = np.random.default_rng(0)
     x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
@@ -50,7 +54,7 @@ def test_numerics_spec_host_device_bits(hip, oracle, fn, lo, hi):
     code = 8 if fn == "swish_packed" else oracle._MATH_FN[fn]
     nat.check(nat.lib().az_math_apply(code, x.size, nat.ptr(xd), nat.ptr(yd), nat.stream_ptr()))
     y = yd.cpu().numpy()
-    ref = oracle.math_apply("swish" if fn == "swish_packed" else fn, x)
+    ref = oracle.math_apply({"swish_packed": "swish", "sin_select": "sin", "cos_select": "cos"}.get(fn, fn), x)
     same = (y.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(y) & np.isnan(ref))
     assert same.all(), (fn, x[~same][:5], y[~same][:5], ref[~same][:5])
 

@@ -278,3 +278,18 @@ def test_numerics_spec_special_values(oracle):
     x = np.linspace(-103.9, -87.4, 1000).astype(np.float32)
     y = oracle.math_apply("exp", x).astype(np.float64)
     assert np.all(np.abs(y - np.exp(x.astype(np.float64))) <= 1.5e-45 + 2e-7 * y)
+
+
+def test_select_only_trig_equals_the_early_return_forms(oracle):
+    """az_trig_(x, want_cos) -- one body for sine and cosine, selects only, the form the Acrobot
+    step evaluates four at a time -- gives the bits of az_sinf / az_cosf on random bit patterns of
+    every exponent, on the arguments an environment sees, and on the special values."""
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2 ** 32, 1 << 21, dtype=np.uint64).astype(np.uint32)
+    x = np.concatenate([bits.view(np.float32), rng.uniform(-40, 40, 1 << 20).astype(np.float32),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 8192.0, 8192.5, -8193.0,
+                                  1073741824.0, 1073741760.0, -1073741824.0, 1e-45, 3.4e38],
+                                 np.float32)])
+    for sel, plain in (("sin_select", "sin"), ("cos_select", "cos")):
+        a, b = oracle.math_apply(sel, x), oracle.math_apply(plain, x)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), sel
