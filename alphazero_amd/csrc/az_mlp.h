@@ -398,41 +398,6 @@ AZ_DEV void az_mlp_table_decode(uint32_t mine, MlpUnit& u, MlpPre& pre) {
   pre = y.p;
 }
 
-#ifdef AZ_WATCHDOG
-// Diagnostic build only (-DAZ_WATCHDOG): every loop that contains a barrier checks a cycle
-// budget; a wave past the budget logs where it is and ends, so the kernel cannot hang.
-__device__ int az_wd_log[64][8];
-__device__ int az_wd_n;
-#define AZ_WD_LIMIT (1ll << 28)
-AZ_DEV void az_wd_check(const float* t0_slot, int site, int a, int b, int c, int d) {
-  // wave-uniform on purpose (scalar compare and branch): the check must not change how the
-  // surrounding code waits for its memory operations
-  const int lo = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t0_slot)[0]);
-  const int hi = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t0_slot)[1]);
-  const long long t0 = ((long long)hi << 32) | (unsigned)lo;
-  if ((long long)__builtin_amdgcn_s_memtime() - t0 > AZ_WD_LIMIT) {
-    if ((threadIdx.x & 63) == 0) {
-      const int k = atomicAdd(&az_wd_n, 1);
-      if (k < 64) {
-        az_wd_log[k][0] = blockIdx.x;
-        az_wd_log[k][1] = threadIdx.x >> 6;
-        az_wd_log[k][2] = site;
-        az_wd_log[k][3] = a;
-        az_wd_log[k][4] = b;
-        az_wd_log[k][5] = c;
-        az_wd_log[k][6] = d;
-      }
-    }
-    __builtin_amdgcn_endpgm();
-  }
-}
-#define AZ_WD(slot, site, a, b, c, d) az_wd_check(slot, site, a, b, c, d)
-#else
-#define AZ_WD(slot, site, a, b, c, d) \
-  do {                                \
-  } while (0)
-#endif
-
 // Workgroup barrier that publishes LDS writes but leaves the weight prefetch (global
 // loads into registers) in flight: a plain __syncthreads() would drain it.
 AZ_DEV void az_lds_barrier() {
@@ -857,7 +822,6 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
   (void)wave_;
   AZ_STAMP_AT();
   for (int b = 0; b < lead; ++b) {
-    AZ_WD(s.norm_std + 60, 2, b, lead, n_tab, 0);
     az_lds_barrier();
   }
   // the unit whose weights the refills of unit ui fetch: the next one, or (past the last) the
@@ -872,7 +836,6 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
     az_mlp_first_unit(u0, F, s.base, lane);
     AZ_STAMP_AT();
     for (int b = 0; b < u0.bars; ++b) {
-      AZ_WD(s.norm_std + 60, 3, b, u0.bars, 0, n_tab);
       az_lds_barrier();
     }
     AZ_STAMP_AT();
@@ -881,7 +844,6 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
   // behind the phase barrier only its broadcast into scalar registers is left.
   uint32_t mine = n_tab > first ? az_mlp_table_read(s, wave, first, ipre_of(first), lane) : 0u;
   for (int ui = first; ui < n_tab; ++ui) {
-    AZ_WD(s.norm_std + 60, 1, ui, n_tab, lead, 0);
     MlpUnit cur;
     MlpPre pre;
     az_mlp_table_decode(mine, cur, pre);
@@ -897,7 +859,6 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
     az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
     AZ_STAMP_AT();
     for (int b = 0; b < cur.bars; ++b) {
-      AZ_WD(s.norm_std + 60, 3, b, cur.bars, ui, n_tab);
       az_lds_barrier();
     }
     AZ_STAMP_AT();
