@@ -339,11 +339,18 @@ static __device__ __align__(256) float scratch[AZ_REPLAY_SCRATCH_FLOATS];
 static std::mutex g_scratch_mutex;
 static float* g_scratch_ptr[AZ_MAX_DEVICES];
 
-static int az_replay_scratch(float** out) {
+static int az_replay_scratch(hipStream_t stream, float** out) {
   int dev = -1;
   AZ_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= AZ_MAX_DEVICES)
     return az_fail(AZ_ERR_UNSUPPORTED, "device ordinal %d outside [0,%d)", dev, AZ_MAX_DEVICES);
+  if (stream != nullptr) {
+    // the kernels run on the stream's device and must be handed THAT device's copy of the array
+    hipDevice_t sdev = -1;
+    AZ_HIP(hipStreamGetDevice(stream, &sdev));
+    if ((int)sdev != dev)
+      return az_fail(AZ_ERR_INVALID, "the stream belongs to device %d, the current device is %d", (int)sdev, dev);
+  }
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[dev]) {
     void* p = nullptr;
@@ -366,7 +373,7 @@ extern "C" int az_replay_sample_prioritized_noalloc(const az_replay* r, const az
                    "use az_replay_sample_prioritized with caller-provided scratch",
                    AZ_REPLAY_NOALLOC_MAX_CAP, r->cap);
   float* base = nullptr;
-  if (int rc = az_replay_scratch(&base)) return rc;
+  if (int rc = az_replay_scratch((hipStream_t)stream, &base)) return rc;
   az_replay rr = *r;  // the caller's cum / partial are not used (they may be null)
   rr.cum = base;
   rr.partial = base + AZ_REPLAY_NOALLOC_MAX_CAP;

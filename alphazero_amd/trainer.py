@@ -60,6 +60,8 @@ class Config:
     vf_cost: float = 0.5
     l2_coef: float = 1e-4
     normalize_observations: bool = True
+    num_eval_envs: int = 64            # alphazero.py:56
+    deterministic_eval: bool = True
 
 
 class Trainer:
@@ -109,9 +111,10 @@ class Trainer:
         mean, std = (self.stats.mean, self.stats.std) if self.cfg.normalize_observations else (None, None)
         self.model.update(self.policy_layers, self.value_layers, mean, std)
 
-    def actor_step(self, key, deterministic=False):
-        """alphazero.py:287-403: search on the current states, act, step the environment."""
-        cfg, st = self.cfg, self.env_state
+    def actor_step(self, key, deterministic=False, state=None):
+        """alphazero.py:287-403: search on the states `state` (default: the training
+        environments' current ones), act, step the environment."""
+        cfg, st = self.cfg, self.env_state if state is None else state
         _, _, key = prng.split(key, 3)   # key, logits_rng, search_rng (:298); the search takes the third
         logits, value = self.model.forward(st.obs)
         root = RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
@@ -134,7 +137,8 @@ class Trainer:
             self.trace.append(dict(obs=obs, real_obs=real_obs, value=value, action=action,
                                    action_weights=out.action_weights, search_value=search_value,
                                    prior_log_prob=log_prob, reward=nst.reward, done=nst.done,
-                                   truncation=nst.truncation, next_real_obs=nst.real_obs))
+                                   truncation=nst.truncation, next_real_obs=nst.real_obs,
+                                   steps=nst.steps))
         ones = torch.ones_like(nst.reward)
         tr = dict(observation=obs, real_obs=real_obs, action=action.float(), reward=nst.reward,
                   discount=1 - nst.done, next_observation=nst.real_obs,
@@ -165,10 +169,12 @@ class Trainer:
             return L.compute_gae(**kw, lambda_=cfg.gae_lambda, discount=cfg.n_step_gamma)
         return L.n_step_bootstrapped_targets(**kw, n=cfg.n_step_n, gamma=cfg.n_step_gamma)
 
-    def collect(self, k_unroll, k_boot):
-        """alphazero.py:1104-1151: unroll, bootstrap search, targets, priorities, insert."""
+    def collect(self, k_unroll, k_boot, length=None):
+        """alphazero.py:1104-1151: unroll of `length` actor steps (default Config.unroll_length),
+        bootstrap search, targets, priorities, insert."""
         cfg = self.cfg
-        data = self.generate_unroll(k_unroll, cfg.unroll_length)
+        length = cfg.unroll_length if length is None else int(length)
+        data = self.generate_unroll(k_unroll, length)
         saved = self.env_state
         _, boot = self.actor_step(k_boot)       # the extra search only provides the bootstrap value
         self.env_state = saved
@@ -180,7 +186,7 @@ class Trainer:
         flat = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in data.items()}
         rows = L.pack_rows(self.layout, flat)
         self.replay.insert(self.buffer_state, rows)
-        self.env_steps += cfg.unroll_length * self.lanes * self.world
+        self.env_steps += length * self.lanes * self.world
         return flat
 
     # -------------------------------------------------------------- training
@@ -219,25 +225,63 @@ class Trainer:
         return out
 
     def prefill(self):
-        """alphazero.py:1224-1296: collect without learning until min_replay_size rows."""
-        while self.replay.size(self.buffer_state) * self.world < self.cfg.min_replay_size:
-            k_unroll, k_boot, self.key = prng.split(self.key, 3)    # alphazero.py:1229
-            self.collect(k_unroll, k_boot)
+        """alphazero.py:1224-1296 as the driver calls it (:845, :1427-1431): ONE unroll of
+        ceil(min_replay_size / num_envs) actor steps with one 3-way key split and one bootstrap
+        search, inserted without learning; then the observation statistics take the prefilled
+        observations (summed over the ranks) and self-play switches to them.  The driver splits
+        its key in two and drops the key the prefill hands back (:1428-1431).  Returns the
+        number of actor steps."""
+        cfg = self.cfg
+        steps = -(-cfg.min_replay_size // (self.lanes * self.world))     # np.ceil (:845)
+        if steps <= 0:
+            return 0
+        prefill_key, self.key = prng.split(self.key, 2)
+        k_unroll, k_boot, _ = prng.split(prefill_key, 3)                 # :1229
+        flat = self.collect(k_unroll, k_boot, length=steps)
+        if cfg.normalize_observations:
+            self.stats.update(flat["observation"])
+            self._refresh_model()
+        return steps
 
-    def evaluate(self, num_steps):
-        """alphazero.py:433-508 in short: greedy actions, mean reward per step and the number
-        of finished episodes over `num_steps` actor steps."""
-        saved = self.env_state
-        key, reward, episodes = prng.split(self.key, 2)[1], 0.0, 0.0
-        for _ in range(num_steps):
-            key, sub = prng.split(key, 2)
-            self.env_state, tr = self.actor_step(sub, deterministic=True)
-            reward += float(tr["reward"].mean())
-            episodes += float((1 - tr["discount"]).sum())
-        self.env_state = saved
-        return dict(mean_reward=reward / num_steps, episodes=episodes)
+    def evaluate(self, key=None, num_eval_envs=None, episode_length=None):
+        """alphazero.py:433-508 (Evaluator.run_evaluation) with the accumulation of EvalWrapper
+        (envs/brax_wrappers.py:153-197): `num_eval_envs` fresh environments run one unroll of
+        `episode_length` actor steps (greedy actions when Config.deterministic_eval); every lane
+        adds up the rewards of its FIRST episode and records that episode's length.  Runs on
+        this rank's device only, like the reference's evaluator (process 0, one device)."""
+        cfg = self.cfg
+        n = cfg.num_eval_envs if num_eval_envs is None else int(num_eval_envs)
+        length = cfg.episode_length if episode_length is None else int(episode_length)
+        if key is None:
+            self.key, key = prng.split(self.key, 2)
+        t0 = time.perf_counter()
+        st = self.env.reset(key, batch_size=n, device=self.device)      # split(key, num_eval_envs) (:460)
+        active = torch.ones_like(st.reward)
+        episode_reward = torch.zeros_like(st.reward)
+        episode_steps = torch.zeros_like(st.reward)
+        for _ in range(length):
+            sub, key = prng.split(key, 2)                                # generate_unroll (:422)
+            st, _ = self.actor_step(sub, deterministic=cfg.deterministic_eval, state=st)
+            episode_steps = torch.where(active != 0, st.steps, episode_steps)
+            episode_reward = episode_reward + st.reward * active
+            active = active * (1 - st.done)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        dt = time.perf_counter() - t0
+        return {"eval/episode_reward": float(episode_reward.mean()),
+                "eval/episode_reward_std": float(episode_reward.std(unbiased=False)),   # np.std
+                "eval/avg_episode_length": float(episode_steps.mean()),
+                "eval/sps": length * n / dt,                             # :473, :500
+                "episode_reward": episode_reward, "episode_steps": episode_steps,
+                "active_episodes": active}
 
     def train(self, num_training_steps, log=None):
+        """The driver's loop (alphazero.py:1425-1470) without its logging: prefill once while the
+        replay queue holds fewer than min_replay_size rows over all ranks, then training steps."""
+        if self.cfg.min_replay_size > 0 and \
+                int(parallel.sum_over_ranks(int(self.replay.size(self.buffer_state)), device=self.device)) \
+                < self.cfg.min_replay_size:
+            self.prefill()
         t0 = time.perf_counter()
         steps0 = self.env_steps
         m = {}

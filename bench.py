@@ -18,7 +18,6 @@ max-over-ranks of the elapsed time.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import threading
@@ -61,11 +60,10 @@ def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher's environment: run the N ranks as a
     torch.distributed.run child process and exit with its code.  Called before anything in this
     process initialises the GPU; nothing is exec'ed."""
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    # (--standalone: the launcher's own rendezvous picks a free port itself; probing one here
+    # and handing its number on would leave a window in which another process can take it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--local-addr", "127.0.0.1",
            os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd))
 

@@ -78,7 +78,10 @@ int az_replay_sample_prioritized(const az_replay* r, const az_replay_state* st,
  * for queues of at most AZ_REPLAY_NOALLOC_MAX_CAP rows (about 4 MiB per GPU the library runs
  * on, kept until the process ends); larger queues are refused with AZ_ERR_UNSUPPORTED.  The
  * call allocates nothing.  All calls on one GPU share that array: calls that overlap on one GPU
- * (different streams or threads) race. */
+ * (different streams or threads) race.  `stream` must belong to the current device
+ * (AZ_ERR_INVALID otherwise).  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress, which may load the code object): make that one call outside graph
+ * capture; later calls on the device only launch kernels. */
 #define AZ_REPLAY_NOALLOC_MAX_CAP (1 << 20)
 int az_replay_sample_prioritized_noalloc(const az_replay* r, const az_replay_state* st,
                                          const uint32_t sample_key[2], float beta, int32_t bs,

@@ -77,3 +77,23 @@ def refreshed_priorities(batch, value_layers, mean, std, per_alpha):
         batch["bootstrap_value"]
     values = ln.mlp(value_layers, (batch["observation"] - mean) / std)
     return ln.priorities(targets, values, per_alpha)
+
+
+def eval_metrics(steps):
+    """alphazero.py:476-506 over an evaluation unroll whose environment is wrapped in EvalWrapper
+    (envs/brax_wrappers.py:153-197): `steps` are the recorded stepped states in order, each with
+    reward [B], done [B] and steps [B] (info['steps'] of EpisodeWrapper, :81-97).  A lane is
+    active until its first done; while active its rewards are added up and its step counter
+    is copied."""
+    n = steps[0]["reward"].shape[0]
+    active = np.ones(n)                   # reset (:156-167)
+    episode_reward = np.zeros(n)
+    episode_steps = np.zeros(n)
+    for s in steps:                       # step (:169-197)
+        episode_steps = np.where(active != 0, s["steps"], episode_steps)
+        episode_reward = episode_reward + s["reward"] * active
+        active = active * (1 - s["done"])
+    return {"episode_reward": episode_reward, "episode_steps": episode_steps, "active_episodes": active,
+            "eval/episode_reward": float(np.mean(episode_reward)),
+            "eval/episode_reward_std": float(np.std(episode_reward)),
+            "eval/avg_episode_length": float(np.mean(episode_steps))}

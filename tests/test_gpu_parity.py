@@ -234,6 +234,7 @@ FUSED_CASES = [
     ("CartPole-v1", "gumbel", 40, 16, 1, {}),
     ("CartPole-v1", "gumbel", 20, 256, 1, {}),   # the S of the largest baseline configuration
     ("CartPole-v1", "muzero", 16, 12, 1, {}),
+    ("CartPole-v1", "muzero", 64, 32, 1, {}),    # the smallest baseline configuration (64 lanes x 32 simulations, PUCT)
     ("CartPole-v1", "gumbel", 16, 12, 1, dict(qt_kwargs=dict(use_mixed_value=False))),
     ("MountainCar-v0", "muzero", 16, 12, 1, {}),
     ("Acrobot-v1", "gumbel", 16, 12, 1, {}),

@@ -16,7 +16,7 @@ def test_training_steps_run_and_learn_signal(policy, use_gae, atoms, per_alpha):
     from alphazero_amd.trainer import Config, Trainer
     cfg = Config(env_id="CartPole-v1", num_envs=64, unroll_length=6, num_simulations=16, policy=policy,
                  use_gae=use_gae,
-                 num_atoms=atoms, per_alpha=per_alpha, max_replay_size=2048,
+                 num_atoms=atoms, per_alpha=per_alpha, max_replay_size=2048, min_replay_size=0,
                  replay_buffer_batch_size=32, num_minibatches=4, value_hidden=(64, 64),
                  policy_hidden=(32, 32), num_samples=8)
     tr = Trainer(cfg, device="cuda")
@@ -33,8 +33,8 @@ def test_training_steps_run_and_learn_signal(policy, use_gae, atoms, per_alpha):
     ref, _ = L.forward_networks(tr.policy_layers, tr.value_layers, tr.stats.mean, tr.stats.std,
                                 tr.env_state.obs)
     torch.testing.assert_close(lg, ref, rtol=1e-4, atol=1e-5)
-    ev = tr.evaluate(4)
-    assert ev["mean_reward"] > 0
+    ev = tr.evaluate(num_eval_envs=16, episode_length=12)
+    assert ev["eval/episode_reward"] > 0 and ev["eval/avg_episode_length"] > 0
 
 
 @pytest.mark.parametrize("env_id,use_gae", [("Acrobot-v1", False), ("MountainCar-v0", True),
@@ -82,7 +82,7 @@ def _dp_worker(rank, world, port, out):
     try:
         from alphazero_amd.trainer import Config, Trainer
         cfg = Config(env_id="CartPole-v1", num_envs=64, unroll_length=4, num_simulations=8, policy="gumbel",
-                     use_gae=False,
+                     use_gae=False, min_replay_size=0,
                      max_replay_size=2048, replay_buffer_batch_size=32, num_minibatches=2,
                      value_hidden=(64, 64), policy_hidden=(32, 32), per_alpha=0.6)
         tr = Trainer(cfg, device="cuda:0")
@@ -192,3 +192,93 @@ def test_training_step_plumbing_vs_restatement(use_gae, atoms):
     assert np.array_equal(after[untouched, -2], before[untouched, -2])
     # rows themselves are not modified by the learner
     assert np.array_equal(after[:, :-2], before[:, :-2])
+
+
+def test_prefill_is_one_unroll_and_updates_the_normaliser():
+    """alphazero.py:845, 1224-1296, 1427-1431: the prefill is ONE unroll of
+    ceil(min_replay_size / num_envs) actor steps with one bootstrap search; afterwards the
+    observation statistics hold the prefilled observations and self-play uses them; the trainer's
+    key advances by one 2-way split.  train() prefills only while the queue is below
+    min_replay_size.  (Parity unpinned: the reference has no test of this path.)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd import learner as L
+    from alphazero_amd import prng
+    from alphazero_amd.trainer import Config, Trainer
+    cfg = Config(env_id="CartPole-v1", num_envs=64, unroll_length=4, num_simulations=8, policy="gumbel",
+                 use_gae=True, max_replay_size=2048, min_replay_size=1000, replay_buffer_batch_size=32,
+                 num_minibatches=4, value_hidden=(64, 64), policy_hidden=(32, 32), seed=5)
+    tr = Trainer(cfg, device="cuda")
+    key0 = tr.key
+    tr.trace = []
+    assert tr.prefill() == 16                                   # ceil(1000 / 64)
+    assert len(tr.trace) == 16 + 1                              # one unroll + ONE bootstrap search
+    tr.trace = None
+    assert int(tr.replay.size(tr.buffer_state)) == 16 * 64
+    assert tr.env_steps == 16 * 64 and float(tr.stats.count) == 16 * 64
+    assert tr.key == prng.split(key0, 2)[1]
+    assert tr.optimizer.count == 0                              # no learning during the prefill
+    lg, _ = tr.model.forward(tr.env_state.obs)                  # self-play sees the new statistics
+    ref, _ = L.forward_networks(tr.policy_layers, tr.value_layers, tr.stats.mean, tr.stats.std,
+                                tr.env_state.obs)
+    torch.testing.assert_close(lg, ref, rtol=1e-4, atol=1e-5)
+    assert float(tr.stats.std.max()) < 0.9                      # no longer the initial ones
+    m = tr.train(1)                                             # the queue is full enough: no second prefill
+    assert m["buffer_current_size"] == 16 * 64 + 4 * 64
+    tr2 = Trainer(cfg, device="cuda")                           # train() on an empty queue prefills first
+    m2 = tr2.train(1)
+    assert m2["buffer_current_size"] == 16 * 64 + 4 * 64 and tr2.env_steps == tr.env_steps
+
+
+def test_evaluate_follows_the_eval_wrapper_accumulation():
+    """alphazero.py:433-508 with envs/brax_wrappers.py:153-197: per evaluation lane the return and
+    the length of its FIRST episode, against the NumPy restatement on the recorded transitions
+    (episodes of at most 9 steps inside an unroll of 30, so lanes auto-reset several times)."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd.trainer import Config, Trainer
+    from oracle import trainer_numpy as tn
+    cfg = Config(env_id="CartPole-v1", num_envs=16, unroll_length=2, num_simulations=8, policy="gumbel",
+                 min_replay_size=0, max_replay_size=256, replay_buffer_batch_size=8, num_minibatches=2,
+                 value_hidden=(32, 32), policy_hidden=(16, 16), episode_length=9, num_eval_envs=48, seed=2)
+    tr = Trainer(cfg, device="cuda")
+    state_before = tr.env_state
+    tr.trace = []
+    ev = tr.evaluate(episode_length=30)
+    steps = [{k: v.double().cpu().numpy() for k, v in s.items() if k in ("reward", "done", "steps")}
+             for s in tr.trace]
+    tr.trace = None
+    assert len(steps) == 30 and steps[0]["reward"].shape == (48,)
+    assert tr.env_state is state_before                        # the training environments are untouched
+    ref = tn.eval_metrics(steps)
+    assert np.array_equal(ev["episode_reward"].cpu().numpy(), ref["episode_reward"].astype(np.float32))
+    assert np.array_equal(ev["episode_steps"].cpu().numpy(), ref["episode_steps"].astype(np.float32))
+    assert np.array_equal(ev["active_episodes"].cpu().numpy(), ref["active_episodes"].astype(np.float32))
+    assert ev["eval/episode_reward"] == pytest.approx(ref["eval/episode_reward"], rel=1e-6)
+    assert ev["eval/episode_reward_std"] == pytest.approx(ref["eval/episode_reward_std"], rel=1e-5, abs=1e-6)
+    assert ev["eval/avg_episode_length"] == pytest.approx(ref["eval/avg_episode_length"], rel=1e-6)
+    # every lane finished its first episode within 9 steps (EpisodeWrapper truncates there)
+    assert float(ev["active_episodes"].sum()) == 0 and float(ev["episode_steps"].max()) <= 9
+    assert ev["eval/sps"] > 0
+
+
+def test_training_step_at_the_largest_configuration():
+    """One training step at the size of the largest baseline configuration (16 384 lanes x 256
+    simulations, Gumbel policy; unroll of one actor step and a small SGD batch to keep it short):
+    finite metrics, one row per lane in the queue."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd.trainer import Config, Trainer
+    cfg = Config(env_id="CartPole-v1", num_envs=16384, unroll_length=1, num_simulations=256, policy="gumbel",
+                 use_gae=True, min_replay_size=0, max_replay_size=32768, replay_buffer_batch_size=64,
+                 num_minibatches=2, per_alpha=0.6, seed=4)
+    tr = Trainer(cfg, device="cuda")
+    m = tr.training_step()
+    torch.cuda.synchronize()
+    assert all(math.isfinite(float(v)) for v in m.values()), m
+    assert int(m["buffer_current_size"]) == 16384 and tr.env_steps == 16384
+    assert float(tr.stats.count) == 16384

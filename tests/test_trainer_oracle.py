@@ -55,3 +55,18 @@ def test_refreshed_priorities_use_the_given_networks_and_statistics():
     p = tn.refreshed_priorities(batch, layers, mean=np.array([1.0, 0.0]), std=np.array([2.0, 1.0]), per_alpha=1.0)
     # value = 2 * (3 - 1) / 2 + 1 = 3; target = 1 + 0.5 * 4 = 3
     np.testing.assert_allclose(p, [1e-10])
+
+
+def test_eval_metrics_count_the_first_episode_only():
+    """Two lanes over four steps: lane 0 ends its first episode at step 2 (what follows belongs to
+    the auto-reset episode and is not counted), lane 1 never ends."""
+    f = np.float64
+    steps = [dict(reward=np.array([1.0, 2.0], f), done=np.array([0.0, 0.0], f), steps=np.array([1.0, 1.0], f)),
+             dict(reward=np.array([1.0, 2.0], f), done=np.array([1.0, 0.0], f), steps=np.array([2.0, 2.0], f)),
+             dict(reward=np.array([5.0, 2.0], f), done=np.array([0.0, 0.0], f), steps=np.array([1.0, 3.0], f)),
+             dict(reward=np.array([5.0, 2.0], f), done=np.array([1.0, 0.0], f), steps=np.array([2.0, 4.0], f))]
+    m = tn.eval_metrics(steps)
+    assert list(m["episode_reward"]) == [2.0, 8.0] and list(m["episode_steps"]) == [2.0, 4.0]
+    assert list(m["active_episodes"]) == [0.0, 1.0]
+    assert m["eval/episode_reward"] == 5.0 and m["eval/episode_reward_std"] == 3.0
+    assert m["eval/avg_episode_length"] == 3.0

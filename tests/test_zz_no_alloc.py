@@ -70,6 +70,36 @@ def test_noalloc_sampling_equals_the_allocating_entry_point():
         assert len(set(ri.tolist())) > 1
 
 
+def test_noalloc_sampling_allocates_no_device_memory_and_covers_the_maximum_capacity():
+    """A queue of exactly the stated maximum (2^20 rows: every chunk slot of the library's scratch
+    array, up to its last words, is in use) against the allocating entry point, and the free
+    device memory before and after a call, which must not move (the outputs are allocated by
+    the test beforehand; one earlier call has looked the scratch address up)."""
+    import torch
+    from alphazero_amd import _native as nat
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    lib = nat.lib()
+    cap, D, n_rows, bs = 1 << 20, 3, (1 << 20) - 5, 512
+    ref_desc, ref_st, ref_t = _queue(torch, nat, cap, D, n_rows, 7, True)
+    new_desc, new_st, new_t = _queue(torch, nat, cap, D, n_rows, 7, False)
+    ri, rb = _sample(torch, nat, lib.az_replay_sample_prioritized, ref_desc, ref_st, (9, 9), 0.5, bs, D)
+    ni, nb = _sample(torch, nat, lib.az_replay_sample_prioritized_noalloc, new_desc, new_st, (9, 9), 0.5, bs, D)
+    assert np.array_equal(ri, ni) and np.array_equal(rb, nb)
+    assert np.array_equal(ref_t["weight"].cpu().numpy(), new_t["weight"].cpu().numpy())
+    assert int(ni.max()) > cap - cap // 64                      # draws reach the last chunks
+    idx = torch.empty(bs, dtype=torch.int32, device="cuda")
+    batch = torch.empty((bs, D), device="cuda")
+    k = (C.c_uint32 * 2)(11, 12)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    nat.check(lib.az_replay_sample_prioritized_noalloc(C.byref(new_desc), C.byref(new_st), C.byref(k), 0.5, bs,
+                                                       nat.ptr(idx), nat.ptr(batch), nat.stream_ptr()))
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before
+
+
 def test_noalloc_sampling_refuses_queues_beyond_its_scratch():
     import torch
     from alphazero_amd import _native as nat
