@@ -66,7 +66,7 @@ class Model(C.Structure):
                 ("num_actions", C.c_int32), ("num_atoms", C.c_int32),
                 ("policy_layers", C.c_int32), ("value_layers", C.c_int32),
                 ("policy_sizes", C.c_int32 * (MAX_LAYERS + 1)),
-                ("value_sizes", C.c_int32 * (MAX_LAYERS + 1)),
+                ("value_sizes", C.c_int32 * (MAX_LAYERS + 1)), ("hidden_bf16", C.c_int32),
                 ("packed", C.c_void_p), ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p)]
 
 
@@ -116,6 +116,8 @@ SIGNATURES = {
                                      _P, _P, _P, _P]),
     "az_model_packed_floats": (C.c_int64, [C.POINTER(MlpParams), C.POINTER(MlpParams)]),
     "az_model_pack": (C.c_int, [C.POINTER(MlpParams), C.POINTER(MlpParams), _P, _P]),
+    "az_model_packed_floats_bf16": (C.c_int64, [C.POINTER(MlpParams), C.POINTER(MlpParams)]),
+    "az_model_pack_bf16": (C.c_int, [C.POINTER(MlpParams), C.POINTER(MlpParams), _P, _P]),
     "az_forward": (C.c_int, [C.POINTER(Model), _I, _P, _P, _P, _P]),
     "az_recurrent_step": (C.c_int, [C.POINTER(Model), _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "az_search_fused": (C.c_int, [C.POINTER(SearchDesc), C.POINTER(TreePtrs),

@@ -28,11 +28,28 @@ static int az_check_mlp(const az_mlp_params* p, const char* name) {
   return AZ_OK;
 }
 
-extern "C" int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params* value) {
+// Hidden layers in bfloat16 need input widths that fill whole k-blocks of 32.
+static int az_check_bf16(const az_mlp_params* p, const char* name) {
+  for (int i = 1; i <= p->n_layers - 2; ++i)
+    if (p->sizes[i] % 32)
+      return az_fail(AZ_ERR_UNSUPPORTED,
+                     "bfloat16 hidden layers need widths that are multiples of 32: %s layer %d has %d inputs",
+                     name, i, p->sizes[i]);
+  return AZ_OK;
+}
+
+static int64_t az_packed_floats(const az_mlp_params* policy, const az_mlp_params* value, int hidden_bf16) {
   if (az_check_mlp(policy, "policy") || az_check_mlp(value, "value")) return -1;
+  if (hidden_bf16 && (az_check_bf16(policy, "policy") || az_check_bf16(value, "value"))) return -1;
   MlpLayout lp, lv;
-  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &lp);
-  return az_mlp_layout(value->n_layers, value->sizes, off, &lv);
+  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &lp, hidden_bf16);
+  return az_mlp_layout(value->n_layers, value->sizes, off, &lv, hidden_bf16);
+}
+extern "C" int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params* value) {
+  return az_packed_floats(policy, value, 0);
+}
+extern "C" int64_t az_model_packed_floats_bf16(const az_mlp_params* policy, const az_mlp_params* value) {
+  return az_packed_floats(policy, value, 1);
 }
 
 __global__ void k_pack_layer(const float* __restrict__ w, const float* __restrict__ bsrc, int kin,
@@ -52,26 +69,61 @@ __global__ void k_pack_layer(const float* __restrict__ w, const float* __restric
     bp[n] = n < nout ? bsrc[n] : 0.0f;
 }
 
-extern "C" int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
-                             void* stream) {
+// A bfloat16 layer: element ((t * nkb + kb) * 64 + lane) * 8 + j = W[32 kb + 8 (lane >> 4) + j][16 t + (lane & 15)],
+// rounded to nearest even; zero padded.  The bias stays float32.
+__global__ void k_pack_layer_bf16(const float* __restrict__ w, const float* __restrict__ bsrc, int kin,
+                                  int nout, int kp, int np, __bf16* __restrict__ wp, float* __restrict__ bp) {
+  const int64_t total = (int64_t)kp * np;
+  const int nkb = kp >> 5;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const int64_t blk = e >> 9;  // t * nkb + kb
+    const int kb = (int)(blk % nkb), t = (int)(blk / nkb);
+    const int k = 32 * kb + 8 * (lane >> 4) + j, n = 16 * t + (lane & 15);
+    wp[e] = (__bf16)((k < kin && n < nout) ? w[(size_t)k * nout + n] : 0.0f);
+  }
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < np; n += gridDim.x * blockDim.x)
+    bp[n] = n < nout ? bsrc[n] : 0.0f;
+}
+
+static int az_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed, int hidden_bf16,
+                   void* stream) {
   if (int rc = az_check_mlp(policy, "policy")) return rc;
   if (int rc = az_check_mlp(value, "value")) return rc;
+  if (hidden_bf16) {
+    if (int rc = az_check_bf16(policy, "policy")) return rc;
+    if (int rc = az_check_bf16(value, "value")) return rc;
+  }
   if (!packed) return az_fail(AZ_ERR_INVALID, "null packed buffer");
   MlpLayout L[2];
-  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &L[0]);
-  az_mlp_layout(value->n_layers, value->sizes, off, &L[1]);
+  int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &L[0], hidden_bf16);
+  az_mlp_layout(value->n_layers, value->sizes, off, &L[1], hidden_bf16);
   const az_mlp_params* P[2] = {policy, value};
   for (int net = 0; net < 2; ++net)
     for (int i = 0; i < L[net].n_layers; ++i) {
       if (!P[net]->w[i] || !P[net]->b[i]) return az_fail(AZ_ERR_INVALID, "null layer weights");
       const int64_t total = (int64_t)L[net].kp[i] * L[net].np[i];
       const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-      k_pack_layer<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
-          P[net]->w[i], P[net]->b[i], L[net].kin[i], L[net].nout[i], L[net].kp[i], L[net].np[i],
-          packed + L[net].w_off[i], packed + L[net].b_off[i]);
+      if (L[net].wb[i])
+        k_pack_layer_bf16<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            P[net]->w[i], P[net]->b[i], L[net].kin[i], L[net].nout[i], L[net].kp[i], L[net].np[i],
+            reinterpret_cast<__bf16*>(packed + L[net].w_off[i]), packed + L[net].b_off[i]);
+      else
+        k_pack_layer<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            P[net]->w[i], P[net]->b[i], L[net].kin[i], L[net].nout[i], L[net].kp[i], L[net].np[i],
+            packed + L[net].w_off[i], packed + L[net].b_off[i]);
       AZ_LAUNCH_CHECK();
     }
   return AZ_OK;
+}
+extern "C" int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
+                             void* stream) {
+  return az_pack(policy, value, packed, 0, stream);
+}
+extern "C" int az_model_pack_bf16(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
+                                  void* stream) {
+  return az_pack(policy, value, packed, 1, stream);
 }
 
 static int az_model_dev(const az_model* m, ModelDev* md) {
@@ -101,8 +153,13 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   md->obs_dim = od;
   md->A = na;
   md->K = m->num_atoms;
-  int64_t off = az_mlp_layout(pp.n_layers, pp.sizes, 0, &md->pol);
-  az_mlp_layout(vp.n_layers, vp.sizes, off, &md->val);
+  md->bf16 = m->hidden_bf16 ? 1 : 0;
+  if (md->bf16) {
+    if (int rc = az_check_bf16(&pp, "policy")) return rc;
+    if (int rc = az_check_bf16(&vp, "value")) return rc;
+  }
+  int64_t off = az_mlp_layout(pp.n_layers, pp.sizes, 0, &md->pol, md->bf16);
+  az_mlp_layout(vp.n_layers, vp.sizes, off, &md->val, md->bf16);
   int pk = 16, vk = 16;
   for (int i = 0; i < md->pol.n_layers; ++i) pk = md->pol.np[i] > pk ? md->pol.np[i] : pk;
   for (int i = 0; i < md->val.n_layers; ++i) vk = md->val.np[i] > vk ? md->val.np[i] : vk;
@@ -164,6 +221,7 @@ AZ_DEV void az_stage_inputs(const ModelDev& md, const MlpLds& s, int tid, int nt
   az_mlp_stage_heads(md, s, tid, nthreads);
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
                                                                const float* __restrict__ obs,
                                                                float* __restrict__ logits,
@@ -179,8 +237,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   __syncthreads();
   MlpRegs regs;
   MlpFirst first;
-  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs, first, true);
-  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
+  az_forward_prime<AZ_MLP_WAVES, BF16 ? AZ_SLOTS_BF16 : AZ_SLOTS>(md, s, wave, lane, regs, first, true);
+  az_forward_tile<AZ_MLP_WAVES, false, BF16>(md, s, wave, lane, regs, first);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -199,9 +257,9 @@ extern "C" int az_forward(const az_model* m, int32_t B, const float* obs, float*
   if (int rc = az_model_dev(m, &md)) return rc;
   if (B < 1 || !obs || !logits || !value) return az_fail(AZ_ERR_INVALID, "bad forward arguments");
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
-  if (int rc = az_set_lds((const void*)k_forward, lds)) return rc;
-  k_forward<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
-      md, B, obs, logits, value);
+  auto kern = md.bf16 ? k_forward<true> : k_forward<false>;
+  if (int rc = az_set_lds((const void*)kern, lds)) return rc;
+  kern<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(md, B, obs, logits, value);
   AZ_LAUNCH_CHECK();
   return AZ_OK;
 }
@@ -216,6 +274,7 @@ AZ_DEV void az_model_env_step(const ModelDev& md, EnvState& st, int action, EnvO
   discount = md.gamma * (o.truncated != 0.0f ? 1.0f : 1.0f - o.terminated);
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
     ModelDev md, int B, float* __restrict__ state, int32_t* __restrict__ time,
     const int32_t* __restrict__ action, float* __restrict__ reward, float* __restrict__ discount,
@@ -243,8 +302,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   __syncthreads();
   MlpRegs regs;
   MlpFirst first;
-  az_forward_prime<AZ_MLP_WAVES>(md, s, wave, lane, regs, first, true);
-  az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
+  az_forward_prime<AZ_MLP_WAVES, BF16 ? AZ_SLOTS_BF16 : AZ_SLOTS>(md, s, wave, lane, regs, first, true);
+  az_forward_tile<AZ_MLP_WAVES, false, BF16>(md, s, wave, lane, regs, first);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
     for (int k = 0; k < md.K; ++k) value[(size_t)b * md.K + k] = s.value[tid * AZ_MAX_ATOMS + k];
@@ -259,8 +318,9 @@ extern "C" int az_recurrent_step(const az_model* m, int32_t B, float* state, int
   if (B < 1 || !state || !time || !action || !reward || !discount || !logits || !value)
     return az_fail(AZ_ERR_INVALID, "bad recurrent_step arguments");
   const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
-  if (int rc = az_set_lds((const void*)k_recurrent_step, lds)) return rc;
-  k_recurrent_step<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
+  auto kern = md.bf16 ? k_recurrent_step<true> : k_recurrent_step<false>;
+  if (int rc = az_set_lds((const void*)kern, lds)) return rc;
+  kern<<<dim3((B + 15) / 16), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(
       md, B, state, time, action, reward, discount, logits, value);
   AZ_LAUNCH_CHECK();
   return AZ_OK;
@@ -357,7 +417,7 @@ AZ_DEV int az_opaque(int v) {
 // workgroup barrier hands the 16 observations to the networks, and after the networks' last
 // phase every wave updates its own two lanes -- nothing else in the loop crosses a wave.
 // EXACT: A == AMAX and K == KMAX (compile-time shapes); RULE: see az_rule_ctx.
-template <int AMAX, int KMAX, bool EXACT, int RULE, bool NOISY>
+template <int AMAX, int KMAX, bool EXACT, int RULE, bool NOISY, bool BF16 = false>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
     SearchCtx c_in, az_tree t, ModelDev md, int emb_in_lds, unsigned long long* sum_depth) {
   static_assert(AZ_MLP_WAVES * 64 == AZ_TREE_THREADS, "one thread layout for both phases");
@@ -368,10 +428,9 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   MlpLds s(lds, md.pol_kp, md.val_kp, md.tab_units);
   float* tree_lds = lds + az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
+  const int ln = tid / AZ_POS, j = tid & (AZ_POS - 1);
   const int b = blockIdx.x * AZ_WG_LANES + ln;
   const bool active = b < d.B;
-  const bool leader = active && j == 0;
   WaveLds ws(tree_lds, ln, S);
   // With room in LDS, the lane's environment states live there too ([N][5] words: the
   // state and the step counter); global memory keeps a write-through copy for the caller.
@@ -428,7 +487,8 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       // the other seven before it can start its walk)
       MlpFirst first;
       const MlpPre first_unit = az_forward_prime_begin<AZ_MLP_WAVES>(s, wave, lane, first, true);
-      az_forward_prime_slots<0, 6>(first_unit, lane, regs);
+      constexpr int kSlots = BF16 ? AZ_SLOTS_BF16 : AZ_SLOTS;
+      az_forward_prime_slots<0, 6, kSlots>(first_unit, lane, regs);
       Lane<AMAX, KMAX> l(t, active ? b : 0, S + 1, A, K);
       if (NOISY)
         wp = az_wave_chase_flagged<AMAX, KMAX>(c, l, ws, b, h, j, sim, d.max_depth, active,
@@ -436,7 +496,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       else
         wp = az_wave_chase_lean(ws, h, j, sim, d.max_depth, active);
       AZ_SIM_STAMP(1);
-      az_forward_prime_slots<6, 11>(first_unit, lane, regs);
+      az_forward_prime_slots<6, 11, kSlots>(first_unit, lane, regs);
       // Three actions (MountainCar, Acrobot): the lane's first FOUR threads step the environment
       // together -- Acrobot's step is 21 sines and cosines, four at a time with four threads
       // (az_trig4) -- and the first of them alone writes.
@@ -483,7 +543,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
         }
         AZ_SIM_STAMP(8);
       }
-      az_forward_prime_slots<11, AZ_SLOTS>(first_unit, lane, regs);
+      az_forward_prime_slots<11, AZ_SLOTS, kSlots>(first_unit, lane, regs);
       // The path is known now, and the rows the update will need depend on the path only: when a
       // row fits in a few registers its loads are issued before the networks run, so that
       // their latency hides behind the MLPs.
@@ -492,7 +552,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       AZ_SIM_STAMP(2);
       __syncthreads();
       AZ_SIM_STAMP(3);
-      az_forward_tile<AZ_MLP_WAVES, false>(md, s, wave, lane, regs, first);
+      az_forward_tile<AZ_MLP_WAVES, false, BF16>(md, s, wave, lane, regs, first);
       // Nothing is in flight any more (the row prefetch returned long ago), and saying so
       // here costs nothing.  Left unsaid, the compiler has to assume on some paths that the
       // prefetch is still pending when its registers are reused in the next simulation, and
@@ -557,6 +617,28 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
     if (emb_in_lds) lds2 += emb_bytes;
     const bool noisy = d->variant != AZ_VARIANT_GUMBEL && d->noise_mode != AZ_NOISE_ZERO;
     const int rule = az_rule_of(d);
+    if (md.bf16) {
+      // bfloat16 hidden layers: the instantiations of the built-in environments' shapes with a
+      // scalar value head, under the rules the three policies use by default
+      using Kern = void (*)(SearchCtx, az_tree, ModelDev, int, unsigned long long*);
+      Kern kern = nullptr;
+      if (d->K == 1 && d->A == 2) {
+        if (noisy && rule == 2) kern = k_search_fused_wave<2, 1, true, 2, true, true>;
+        if (!noisy && rule == 1) kern = k_search_fused_wave<2, 1, true, 1, false, true>;
+      } else if (d->K == 1 && d->A == 3) {
+        if (noisy && rule == 2) kern = k_search_fused_wave<3, 1, true, 2, true, true>;
+        if (!noisy && rule == 1) kern = k_search_fused_wave<3, 1, true, 1, false, true>;
+      }
+      if (!kern)
+        return az_fail(AZ_ERR_UNSUPPORTED,
+                       "bfloat16 hidden layers: fused search built for 2 or 3 actions, one value atom and the "
+                       "policies' default selection rules only");
+      if (int rc = az_set_lds((const void*)kern, lds2)) return rc;
+      kern<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_MLP_WAVES * 64), lds2,
+             (hipStream_t)stream>>>(c, *t, md, emb_in_lds, reinterpret_cast<unsigned long long*>(sum_depth));
+      AZ_LAUNCH_CHECK();
+      return AZ_OK;
+    }
     return az_dispatch_coop(d->A, d->K, [&]<int AMAX, int KMAX, bool EXACT>() -> int {
       using Kern = void (*)(SearchCtx, az_tree, ModelDev, int, unsigned long long*);
       Kern kern;
@@ -574,6 +656,8 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
       return AZ_OK;
     });
   }
+  if (md.bf16)
+    return az_fail(AZ_ERR_UNSUPPORTED, "bfloat16 hidden layers: the one-thread-per-lane fused search is float32 only");
   return az_dispatch_ak(d->A, d->K, [&]<int AMAX, int KMAX>() -> int {
     if (int rc = az_set_lds((const void*)k_search_fused<AMAX, KMAX>, lds)) return rc;
     k_search_fused<AMAX, KMAX>

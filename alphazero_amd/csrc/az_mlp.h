@@ -57,6 +57,7 @@ struct MlpLayout {
   int n_layers;
   int kin[AZ_MAX_LAYERS], nout[AZ_MAX_LAYERS];
   int kp[AZ_MAX_LAYERS], np[AZ_MAX_LAYERS];
+  int wb[AZ_MAX_LAYERS];  // 1: the layer's weights are packed as bfloat16 (az_mlp_layout)
   int64_t w_off[AZ_MAX_LAYERS], b_off[AZ_MAX_LAYERS];  // float offsets into the packed buffer
 };
 
@@ -65,6 +66,7 @@ struct ModelDev {
   float gamma;
   int obs_dim, A, K;
   int pol_kp, val_kp;  // widest padded layer of each network
+  int bf16;            // 1: hidden layers on the bfloat16 matrix instructions (az_mlp_layout)
   int tab_units;       // units of the busiest wave in one pass over both networks (table rows per wave)
   int head_floats;     // LDS floats of the output heads' staged weights (az_mlp_head_floats), 0: not used
   MlpLayout pol, val;
@@ -76,13 +78,25 @@ struct ModelDev {
 __host__ __device__ inline int az_ceil16(int x) { return (x + 15) & ~15; }
 #define AZ_IN0_STRIDE 68  // row stride of the first layer's input buffer (Kp <= 64, + 4)
 #define AZ_SLOTS 16       // k-blocks of one unit held in registers per tile
+#define AZ_SLOTS_BF16 8   // ... in the kernels of a model with bfloat16 hidden layers (8 x 32 = 256 inputs)
 #define AZ_RIDER_SLOTS 4  // k-blocks of a rider tile
 #define AZ_MLP_WAVES 8    // waves of a workgroup that run the networks
 #define AZ_TABLE_UNITS 16 // unit descriptors per wave in the LDS table
 #define AZ_UNIT_WORDS 36  // 32-bit words of one descriptor (sizeof(MlpUnit) / 4)
+// k-blocks per round of a unit.  With bfloat16 hidden layers a k-block of the 256-wide layers is
+// 32 rows, and the weight stream from L2 -- not the matrix pipe -- bounds a phase: every one of a
+// unit's slots is refilled whether it holds anything or not, so those kernels run 8 slots.
+__host__ __device__ inline int az_mlp_slots(const ModelDev& md) { return md.bf16 ? AZ_SLOTS_BF16 : AZ_SLOTS; }
 
 // Fills `L` from the layer sizes; returns the offset just past this network.
-inline int64_t az_mlp_layout(int n_layers, const int32_t* sizes, int64_t base, MlpLayout* L) {
+// hidden_bf16: the layers between the first and the last one keep their weights as bfloat16 and
+// run on v_mfma_f32_16x16x32_bf16 (inputs rounded to bfloat16 as they are read, float32
+// accumulation, float32 bias and activation function); the first layer -- the observation --
+// and the output layer stay in float32.  One k-block of such a layer is 32 rows and takes the
+// same 1 KiB per output tile as a float32 k-block of 16 rows: lane (n = lane & 15, g = lane >> 4)
+// holds W[32 kb + 8 g + j][16 t + n], j = 0 .. 7.  The host checks that these layers' input widths
+// are multiples of 32 (az_model_dev).
+inline int64_t az_mlp_layout(int n_layers, const int32_t* sizes, int64_t base, MlpLayout* L, int hidden_bf16 = 0) {
   L->n_layers = n_layers;
   int64_t off = base;
   for (int i = 0; i < n_layers; ++i) {
@@ -90,8 +104,9 @@ inline int64_t az_mlp_layout(int n_layers, const int32_t* sizes, int64_t base, M
     L->nout[i] = sizes[i + 1];
     L->kp[i] = az_ceil16(sizes[i]);
     L->np[i] = az_ceil16(sizes[i + 1]);
+    L->wb[i] = hidden_bf16 && i >= 1 && i <= n_layers - 2;
     L->w_off[i] = off;
-    off += (int64_t)L->kp[i] * L->np[i];
+    off += L->wb[i] ? (int64_t)L->kp[i] * L->np[i] / 2 : (int64_t)L->kp[i] * L->np[i];
     L->b_off[i] = off;
     off += L->np[i];
   }
@@ -152,7 +167,9 @@ struct MlpTile {
   int act;            // 1: swish into the next layer's permuted activations; 0: plain [16][out_stride]
 };
 
-enum { AZ_U_VALID = 1, AZ_U_TWO = 2, AZ_U_FIRST = 4, AZ_U_LAST = 8, AZ_U_RIDER = 16 };
+// AZ_U_BF16 / AZ_U_RIDER_BF16: the pair's / the rider's layer is a bfloat16 one (k-blocks of 32)
+enum { AZ_U_VALID = 1, AZ_U_TWO = 2, AZ_U_FIRST = 4, AZ_U_LAST = 8, AZ_U_RIDER = 16, AZ_U_BF16 = 32,
+       AZ_U_RIDER_BF16 = 64 };
 
 // One unit of work: a pair of output tiles of one layer, restricted to one round of
 // AZ_SLOTS k-blocks (layers wider than 16*AZ_SLOTS inputs take several rounds; the
@@ -198,13 +215,14 @@ __host__ __device__ inline PhaseShape az_phase_shape(const ModelDev& md, int pha
 AZ_DEV void az_mlp_tile_in(const ModelDev& md, const MlpLds& s, bool is_val, int phase, int kb_base,
                            int& ap_off, int& in_stride, int& kpq) {
   const MlpLayout& L = is_val ? md.val : md.pol;
+  const int kb_quads = L.wb[phase] ? 8 : 4;  // floats of one k-block in each of the four [k & 3] planes
   const float* a = is_val ? s.va : s.pa;
   const float* b = is_val ? s.vb : s.pb;
   // phase 0 reads in0; phase i > 0 reads the buffer phase i-1 wrote
   const float* in = phase == 0 ? s.in0 : ((phase & 1) ? a : b);
   in_stride = phase == 0 ? AZ_IN0_STRIDE : (is_val ? s.vstride : s.pstride);
   kpq = L.kp[phase] >> 2;
-  ap_off = (int)(in - s.base) + kb_base * 4;
+  ap_off = (int)(in - s.base) + kb_base * kb_quads;
 }
 
 AZ_DEV void az_mlp_tile_out(const ModelDev& md, const MlpLds& s, bool is_val, int phase, int tile,
@@ -234,20 +252,22 @@ AZ_DEV MlpUnit az_mlp_unit(const ModelDev& md, const MlpLds& s, int phase, int i
   const bool is_val = idx < ps.n_val;
   const MlpLayout& L = is_val ? md.val : md.pol;
   const int t0 = is_val ? idx * 2 : ps.n_riders + (idx - ps.n_val) * 2;
-  const int nkb_total = L.kp[phase] >> 4;
-  const int kb_base = round * AZ_SLOTS;
-  u.nkb = nkb_total - kb_base < AZ_SLOTS ? nkb_total - kb_base : AZ_SLOTS;
+  const int nkb_total = L.kp[phase] >> (L.wb[phase] ? 5 : 4);
+  const int slots = az_mlp_slots(md);
+  const int kb_base = round * slots;
+  u.nkb = nkb_total - kb_base < slots ? nkb_total - kb_base : slots;
   const bool two = t0 + 1 < (L.np[phase] >> 4);
   const bool rider = is_val && idx < ps.n_riders && round == 0;
   u.flags = AZ_U_VALID | (two ? AZ_U_TWO : 0) | (round == 0 ? AZ_U_FIRST : 0) |
-            (kb_base + AZ_SLOTS >= nkb_total ? AZ_U_LAST : 0) | (rider ? AZ_U_RIDER : 0);
+            (kb_base + slots >= nkb_total ? AZ_U_LAST : 0) | (rider ? AZ_U_RIDER : 0) |
+            (L.wb[phase] ? AZ_U_BF16 : 0) | (rider && md.pol.wb[phase] ? AZ_U_RIDER_BF16 : 0);
   const az_f32x4* wbase = reinterpret_cast<const az_f32x4*>(md.packed + L.w_off[phase]);
   u.w0 = wbase + ((size_t)t0 * nkb_total + kb_base) * 64;
   u.w1 = two ? u.w0 + (size_t)nkb_total * 64 : u.w0;
   az_mlp_tile_in(md, s, is_val, phase, kb_base, u.ap_off, u.in_stride, u.kpq);
   az_mlp_tile_out(md, s, is_val, phase, t0, u.o0);
   if (rider) {
-    const int nkb2 = md.pol.kp[phase] >> 4;
+    const int nkb2 = md.pol.kp[phase] >> (md.pol.wb[phase] ? 5 : 4);
     u.w2 = reinterpret_cast<const az_f32x4*>(md.packed + md.pol.w_off[phase]) + (size_t)idx * nkb2 * 64;
     u.nkb2 = nkb2;
     az_mlp_tile_in(md, s, false, phase, 0, u.ap2_off, u.in_stride2, u.kpq2);
@@ -278,8 +298,8 @@ AZ_DEV MlpUnit az_mlp_next_unit(const ModelDev& md, const MlpLds& s, int P, int 
                                 int round, bool start, int wave) {
   if (!start) {
     const PhaseShape ps = az_phase_shape(md, phase);
-    const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
-    const int nrounds = ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
+    const MlpLayout& L = idx < ps.n_val ? md.val : md.pol;
+    const int nrounds = ((L.kp[phase] >> (L.wb[phase] ? 5 : 4)) + az_mlp_slots(md) - 1) / az_mlp_slots(md);
     if (round + 1 < nrounds) return az_mlp_unit(md, s, phase, idx, round + 1);
     if (idx + NWAVES < ps.n) return az_mlp_unit(md, s, phase, idx + NWAVES, 0);
     phase += 1;
@@ -334,8 +354,8 @@ inline int az_mlp_units_per_wave(const ModelDev& md) {
     for (int phase = 0; phase < az_mlp_unit_phases(md); ++phase) {
       const PhaseShape ps = az_phase_shape(md, phase);
       for (int idx = wave; idx < ps.n; idx += AZ_MLP_WAVES) {
-        const int kp = idx < ps.n_val ? md.val.kp[phase] : md.pol.kp[phase];
-        units += ((kp >> 4) + AZ_SLOTS - 1) / AZ_SLOTS;
+        const MlpLayout& L = idx < ps.n_val ? md.val : md.pol;
+        units += ((L.kp[phase] >> (L.wb[phase] ? 5 : 4)) + az_mlp_slots(md) - 1) / az_mlp_slots(md);
       }
     }
     most = units > most ? units : most;
@@ -448,19 +468,66 @@ AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& ac
 // the prefetch distance is a whole unit, up to 32 KiB in flight per wave).  There is
 // one copy of this loop on purpose: a second instantiation (say, for single-tile
 // units) makes the register allocator keep two sets of weight slots and spill.
+// The A operand of one bfloat16 k-block (32 inputs) for this lane: inputs 32 kb + 8 g + j, j = 0 .. 7
+// (g = lane >> 4), out of the float32 activations in their [k & 3][k >> 2] order -- two
+// consecutive floats out of each of the four planes -- rounded to bfloat16 (nearest even).
+// `apb` = the lane's row + 2 g, `kpq` = floats per plane.
+typedef __attribute__((ext_vector_type(8))) __bf16 az_bf16x8;
+typedef __attribute__((ext_vector_type(2))) float az_f32x2_;
+struct MlpABf16 {
+  az_f32x2_ p[4];
+};
+AZ_DEV MlpABf16 az_mlp_a_bf16_read(const float* apb, int kpq, int kb) {
+  MlpABf16 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.p[j] = *reinterpret_cast<const az_f32x2_*>(apb + j * kpq + kb * 8);
+  return r;
+}
+AZ_DEV az_bf16x8 az_mlp_a_bf16(const MlpABf16& r) {
+  az_bf16x8 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = (__bf16)r.p[j].x;      // k & 3 = j, first of the two
+    a[4 + j] = (__bf16)r.p[j].y;  // the next four inputs
+  }
+  return a;
+}
+AZ_DEV az_bf16x8 az_as_bf16x8(const az_f32x4& w) { return __builtin_bit_cast(az_bf16x8, w); }
+
+// BF16MODE: the kernel belongs to a model with bfloat16 hidden layers; a unit's flags say which of
+// its parts are (in the other kernels that code does not exist).
+template <bool BF16MODE>
 AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
                              az_f32x4& acc1, az_f32x4& acc2, const float* ap, const float* ap2,
                              int lane) {
   const int nk = next.nkb - 1, nk2 = next.nkb2 > 0 ? next.nkb2 - 1 : 0;
   az_f32x4 a[2];  // A operands of even / odd k-blocks
-  a[0] = *reinterpret_cast<const az_f32x4*>(ap);
+  const bool pair_bf16 = BF16MODE && (u.flags & AZ_U_BF16), rider_bf16 = BF16MODE && (u.flags & AZ_U_RIDER_BF16);
+  // (bfloat16 parts: the same row, counted from input 8 g instead of plane g)
+  const int g = lane >> 4;
+  const float* apb = ap - g * u.kpq + 2 * g;
+  const float* apb2 = ap2 - g * u.kpq2 + 2 * g;
+  MlpABf16 ab[2];
+  if (pair_bf16)
+    ab[0] = az_mlp_a_bf16_read(apb, u.kpq, 0);
+  else
+    a[0] = *reinterpret_cast<const az_f32x4*>(ap);
+  constexpr int kSlots = BF16MODE ? AZ_SLOTS_BF16 : AZ_SLOTS;
 #pragma unroll
-  for (int kb = 0; kb < AZ_SLOTS; ++kb) {
+  for (int kb = 0; kb < kSlots; ++kb) {
+    if (BF16MODE && pair_bf16) {
+      if (kb < u.nkb) {
+        if (kb + 1 < kSlots) ab[(kb + 1) & 1] = az_mlp_a_bf16_read(apb, u.kpq, kb + 1);
+        const az_bf16x8 a8 = az_mlp_a_bf16(ab[kb & 1]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, az_as_bf16x8(R.W0[kb]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, az_as_bf16x8(R.W1[kb]), acc1, 0, 0, 0);
+      }
+    } else
     if (kb < u.nkb) {
       // The A operands of the next k-block are read while this one multiplies --
       // unconditionally, so that the wait below can leave exactly this one read in
       // flight; past the unit's last k-block it reads LDS that is not used.
-      if (kb + 1 < AZ_SLOTS) a[(kb + 1) & 1] = *reinterpret_cast<const az_f32x4*>(ap + (kb + 1) * 4);
+      if (kb + 1 < kSlots) a[(kb + 1) & 1] = *reinterpret_cast<const az_f32x4*>(ap + (kb + 1) * 4);
       const az_f32x4 a4 = a[kb & 1];
       const az_f32x4 b0 = R.W0[kb];
       // a single-tile unit multiplies its tile twice (w1 == w0; acc1 is ignored): a
@@ -475,6 +542,12 @@ AZ_DEV void az_mlp_unit_loop(const MlpUnit& u, const MlpPre& next, MlpRegs& R, a
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, acc1, 0, 0, 0);
     }
+    if (BF16MODE && rider_bf16) {
+      if (kb < AZ_RIDER_SLOTS && kb < u.nkb2) {
+        const az_bf16x8 a8 = az_mlp_a_bf16(az_mlp_a_bf16_read(apb2, u.kpq2, kb));
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, az_as_bf16x8(R.W2[kb < AZ_RIDER_SLOTS ? kb : 0]), acc2, 0, 0, 0);
+      }
+    } else
     if (kb < AZ_RIDER_SLOTS && kb < u.nkb2) {
       const az_f32x4 a2 = *reinterpret_cast<const az_f32x4*>(ap2 + kb * 4);
       const az_f32x4 b2 = R.W2[kb < AZ_RIDER_SLOTS ? kb : 0];
@@ -541,9 +614,10 @@ AZ_DEV void az_mlp_unit_epilogue(const MlpUnit& u, const az_f32x4& acc0, const a
 }
 
 
+template <bool BF16MODE>
 AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az_f32x4& acc0,
                             az_f32x4& acc1, float* lds_base, int lane, int wave_, int& stamp_i) {
-  const bool two = u.flags & AZ_U_TWO, last = u.flags & AZ_U_LAST, rider = u.flags & AZ_U_RIDER;
+  const bool two = u.flags & AZ_U_TWO;
   if (u.flags & AZ_U_FIRST) {
     acc0 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     acc1 = az_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -565,7 +639,7 @@ AZ_DEV void az_mlp_run_unit(const MlpUnit& u, const MlpPre& next, MlpRegs& R, az
   // slots between its partner's matrix instructions.  The k-loop runs above the epilogue's
   // priority.
   __builtin_amdgcn_s_setprio(2);
-  az_mlp_unit_loop(u, next, R, acc0, acc1, acc2, ap, ap2, lane);
+  az_mlp_unit_loop<BF16MODE>(u, next, R, acc0, acc1, acc2, ap, ap2, lane);
   __builtin_amdgcn_s_setprio(0);
   AZ_STAMP_AT();
   az_mlp_unit_epilogue(u, acc0, acc1, acc2, bias0, bias1, bias2, lds_base, lane);
@@ -629,13 +703,14 @@ AZ_DEV MlpPre az_forward_prime_begin(const MlpLds& s, int wave, int lane, MlpFir
   return cur;
 }
 
-template <int KB0, int KB1>
+// (KB1 may exceed the kernel's number of slots, SLOTS: the slots beyond it do not exist)
+template <int KB0, int KB1, int SLOTS = AZ_SLOTS>
 AZ_DEV void az_forward_prime_slots(const MlpPre& cur, int lane, MlpRegs& R) {
   if (cur.nkb <= 0) return;
   // same order and count as a unit's refills
   const int nk = cur.nkb - 1, nk2 = cur.nkb2 > 0 ? cur.nkb2 - 1 : 0;
 #pragma unroll
-  for (int kb = KB0; kb < KB1; ++kb) {
+  for (int kb = KB0; kb < (KB1 < SLOTS ? KB1 : SLOTS); ++kb) {
     const int kc = kb < nk ? kb : nk;
     R.W0[kb] = az_ldg4(cur.w0 + (size_t)kc * 64 + lane);
     R.W1[kb] = az_ldg4(cur.w1 + (size_t)kc * 64 + lane);
@@ -646,11 +721,11 @@ AZ_DEV void az_forward_prime_slots(const MlpPre& cur, int lane, MlpRegs& R) {
   }
 }
 
-template <int NWAVES>
+template <int NWAVES, int SLOTS = AZ_SLOTS>
 AZ_DEV void az_forward_prime(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R, MlpFirst& F,
                              bool allow_direct) {
   const MlpPre cur = az_forward_prime_begin<NWAVES>(s, wave, lane, F, allow_direct);
-  az_forward_prime_slots<0, AZ_SLOTS>(cur, lane, R);
+  az_forward_prime_slots<0, SLOTS, SLOTS>(cur, lane, R);
 }
 
 // The first unit in the direct form (MlpFirst): one k-block per tile out of F.
@@ -811,7 +886,7 @@ AZ_DEV void az_mlp_heads(const ModelDev& md, const MlpLds& s, int wave, int lane
 // workgroup barrier per phase, the last of which makes the results visible to every thread.
 // With WRAP the last unit prefetches the first unit's weights again, so the next call needs
 // no priming (and the direct form of the first unit is not used).
-template <int NWAVES, bool WRAP>
+template <int NWAVES, bool WRAP, bool BF16MODE = false>
 AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int lane, MlpRegs& R,
                             const MlpFirst& F) {
   const int n_tab = __builtin_amdgcn_readfirstlane(s.tab_n[wave]);
@@ -856,7 +931,7 @@ AZ_DEV void az_forward_tile(const ModelDev& md, const MlpLds& s, int wave, int l
     const int un = ui + 1 < n_tab ? ui + 1 : ui;
     mine = az_mlp_table_read(s, wave, un, ipre_of(un), lane);
     AZ_STAMP_AT();
-    az_mlp_run_unit(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
+    az_mlp_run_unit<BF16MODE>(cur, pre, R, acc0, acc1, s.base, lane, wave, stamp_i);
     AZ_STAMP_AT();
     for (int b = 0; b < cur.bars; ++b) {
       az_lds_barrier();

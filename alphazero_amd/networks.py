@@ -51,7 +51,12 @@ class FusedModel:
     changed the parameters."""
 
     def __init__(self, env_id, policy_layers, value_layers, norm_mean=None, norm_std=None,
-                 gamma=0.99):
+                 gamma=0.99, hidden_bf16=False):
+        """hidden_bf16: run the layers between the first and the last one of each network on the
+        bfloat16 matrix instructions (az_model_pack_bf16: bfloat16 weights and inputs, float32
+        accumulation).  Not the reference's arithmetic (float32): results agree to about three
+        digits, and nothing computed this way is comparable bit for bit with the CPU checker."""
+        self.hidden_bf16 = bool(hidden_bf16)
         self.env_id = env_id
         self.code = envs_lib.env_code(env_id)
         self.obs_dim = envs_lib.observation_size(env_id)
@@ -68,11 +73,14 @@ class FusedModel:
         if pp.sizes[pp.n_layers] != self.num_actions:
             raise ValueError("policy output width must equal the number of actions")
         self.num_atoms = int(vp.sizes[vp.n_layers])
-        n = nat.lib().az_model_packed_floats(pp, vp)
+        lib = nat.lib()
+        size_fn, pack_fn = ((lib.az_model_packed_floats_bf16, lib.az_model_pack_bf16) if self.hidden_bf16
+                            else (lib.az_model_packed_floats, lib.az_model_pack))
+        n = size_fn(pp, vp)
         if n < 0:
             nat.check(-2)
         self.packed = torch.empty((n,), dtype=torch.float32, device=device)
-        nat.check(nat.lib().az_model_pack(pp, vp, nat.ptr(self.packed), nat.stream_ptr()))
+        nat.check(pack_fn(pp, vp, nat.ptr(self.packed), nat.stream_ptr()))
         self._keep = keep_p + keep_v  # sources stay alive until the pack kernels have run
         f = dict(dtype=torch.float32, device=device)
         self.norm_mean = (torch.zeros(self.obs_dim, **f) if norm_mean is None
@@ -86,6 +94,7 @@ class FusedModel:
         for i in range(nat.MAX_LAYERS + 1):
             m.policy_sizes[i] = pp.sizes[i]
             m.value_sizes[i] = vp.sizes[i]
+        m.hidden_bf16 = 1 if self.hidden_bf16 else 0
         m.packed = self.packed.data_ptr()
         m.norm_mean = self.norm_mean.data_ptr()
         m.norm_std = self.norm_std.data_ptr()

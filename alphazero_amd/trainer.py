@@ -62,6 +62,9 @@ class Config:
     normalize_observations: bool = True
     num_eval_envs: int = 64            # alphazero.py:56
     deterministic_eval: bool = True
+    # not in the reference: self-play evaluates the networks' hidden layers on the bfloat16 matrix
+    # instructions (networks.FusedModel(hidden_bf16=True)); the learner stays float32
+    selfplay_hidden_bf16: bool = False
 
 
 class Trainer:
@@ -86,7 +89,8 @@ class Trainer:
                                               self.device)
         self.stats = L.RunningStatistics(obs, device=self.device)
         self.model = networks.FusedModel(cfg.env_id, self.policy_layers, self.value_layers,
-                                         self.stats.mean, self.stats.std, gamma=cfg.n_step_gamma)
+                                         self.stats.mean, self.stats.std, gamma=cfg.n_step_gamma,
+                                         hidden_bf16=cfg.selfplay_hidden_bf16)
         self.recurrent_fn = networks.FusedRecurrentFn(self.model)
         self.optimizer = L.ClipAdam(L.flat_leaves(self.policy_layers, self.value_layers),
                                     cfg.learning_rate, cfg.max_grad_norm, cfg.anneal_lr,

@@ -81,12 +81,12 @@ def make_networks(env_id, seed, device):
 class Actor:
     """alphazero.py:287-403 actor_step with the search on the fused HIP path."""
 
-    def __init__(self, env_id, B, S, device, seed=0, variant="gumbel"):
+    def __init__(self, env_id, B, S, device, seed=0, variant="gumbel", hidden_bf16=False):
         import alphazero_amd as mctx
         self.mctx, self.B, self.S, self.variant = mctx, B, S, variant
         self.env = mctx.envs.make(env_id, episode_length=500)
         self.pol, self.val = make_networks(env_id, 1, device)
-        self.model = mctx.FusedModel(env_id, self.pol, self.val, gamma=0.99)
+        self.model = mctx.FusedModel(env_id, self.pol, self.val, gamma=0.99, hidden_bf16=hidden_bf16)
         self.recurrent_fn = mctx.FusedRecurrentFn(self.model)
         self.state = self.env.reset(seed, batch_size=B, device=device)
         self.key = (0, seed)
@@ -129,6 +129,45 @@ def secondary_sampled(args, B, S, device, steps=5):
     kt = float(np.mean([s["events"][0][0].elapsed_time(s["events"][0][1]) for s in ktimes]))
     return {"value": round(B * S * steps / dt, 1), "unit": "simulations/s", "num_samples": 100,
             "ms_per_step": round(dt / steps * 1e3, 4), "search_kernel_ms_per_launch": round(kt, 4)}
+
+
+def secondary_bf16(args, B, S, device, steps=10):
+    """The headline actor step with the networks' hidden layers on the bfloat16 matrix
+    instructions (bfloat16 weights and layer inputs, float32 accumulation, float32 first and last
+    layers): NOT the reference's arithmetic, reported beside the float32 headline with how far
+    its search results are from the float32 kernel's on the same roots and root noise."""
+    import alphazero_amd as mctx
+    actor = Actor(args.env, B, S, device, seed=11, hidden_bf16=True)
+    ref = Actor(args.env, B, S, device, seed=11)
+    # one search each from the same states, prior logits and root Gumbel noise
+    logits, value = ref.model.forward(ref.state.obs)
+    root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=ref.state.embedding)
+    gum = torch.empty_like(logits).exponential_().log_().neg_()
+    kw = dict(max_num_considered_actions=16, qtransform=ref.qtransform, root_gumbel=gum)
+    a = mctx.gumbel_muzero_policy((), 0, root, actor.recurrent_fn, S, **kw)
+    b = mctx.gumbel_muzero_policy((), 0, root, ref.recurrent_fn, S, **kw)
+    agree = float((a.action == b.action).float().mean())
+    dw = float((a.action_weights - b.action_weights).abs().max())
+    dw_mean = float((a.action_weights - b.action_weights).abs().mean())
+    dv = float((a.search_tree.node_values[:, 0] - b.search_tree.node_values[:, 0]).abs().max())
+    for _ in range(2):
+        actor.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ktimes = []
+    for _ in range(steps):
+        stats = {"record_events": True}
+        actor.step(stats)
+        ktimes.append(stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = float(np.mean([s["events"][0][0].elapsed_time(s["events"][0][1]) for s in ktimes]))
+    return {"value": round(B * S * steps / dt, 1), "unit": "simulations/s", "dtype": "bf16w/f32acc",
+            "ms_per_step": round(dt / steps * 1e3, 4), "search_kernel_ms_per_launch": round(kt, 4),
+            "action_agreement_with_f32": round(agree, 4), "max_abs_diff_action_weights": round(dw, 5),
+            "mean_abs_diff_action_weights": round(dw_mean, 6),
+            "max_abs_diff_root_value": round(dv, 5),
+            "note": "hidden layers v_mfma_f32_16x16x32_bf16; first and output layers float32; never the parity path"}
 
 
 def pmc_traffic(kernel):
@@ -310,7 +349,8 @@ def main():
         if world == 1:
             line["roofline_tree_kernel"] = tree_kernel_roofline(B, S, 2, device)
             if not args.no_secondary:
-                line["secondary"] = {"sampled_muzero_policy": secondary_sampled(args, B, S, device)}
+                line["secondary"] = {"sampled_muzero_policy": secondary_sampled(args, B, S, device),
+                                     "gumbel_muzero_policy_bf16_hidden_layers": secondary_bf16(args, B, S, device)}
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)
                 lanes = args.cpu_lanes or 192 * threads  # six runs, ~15 s of wall time in all

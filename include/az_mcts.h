@@ -108,7 +108,10 @@ typedef struct az_model {
   int32_t policy_layers, value_layers;
   int32_t policy_sizes[AZ_MAX_LAYERS + 1];
   int32_t value_sizes[AZ_MAX_LAYERS + 1];
-  const float* packed;    /* device buffer filled by az_model_pack */
+  int32_t hidden_bf16;    /* 0: float32 throughout (the reference's arithmetic); 1: `packed` comes from
+                           * az_model_pack_bf16 and the layers between the first and the last one of
+                           * each network run on the bfloat16 matrix instructions */
+  const float* packed;    /* device buffer filled by az_model_pack / az_model_pack_bf16 */
   const float* norm_mean; /* [obs_dim] */
   const float* norm_std;  /* [obs_dim] */
 } az_model;
@@ -154,6 +157,18 @@ int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params*
 /* Re-lays the flax-layout weights out for the matrix cores into `packed`. */
 int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
                   void* stream);
+
+/* No counterpart in the reference (which computes in float32 throughout): the same buffer with
+ * the weights of the hidden layers -- every layer but the first and the last of each network --
+ * rounded to bfloat16 (nearest even) and laid out for v_mfma_f32_16x16x32_bf16; their inputs are
+ * rounded to bfloat16 as they are read, products are accumulated in float32, biases and
+ * activation functions stay float32, and so do the first layer (the observation) and the output
+ * layer.  Those layers' input widths must be multiples of 32.  A model packed this way sets
+ * az_model.hidden_bf16; its results follow the float32 ones to about three decimal digits and
+ * are NOT bit-comparable with the CPU checker. */
+int64_t az_model_packed_floats_bf16(const az_mlp_params* policy, const az_mlp_params* value);
+int az_model_pack_bf16(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
+                       void* stream);
 
 /* alphazero.py:208-216 forward_networks (observation normalisation of
  * running_statistics.py:183-199, policy and value MLPs of networks/networks.py:153-193)

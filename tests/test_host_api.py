@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(nat.SearchInputs) == 4 * 8
     assert C.sizeof(nat.Injected) == 4 * 8
     assert C.sizeof(nat.MlpParams) == 4 + 9 * 4 + 8 * 8 * 2
-    assert C.sizeof(nat.Model) == 7 * 4 + 2 * 9 * 4 + 4 + 3 * 8  # 4 bytes padding before pointers
+    assert C.sizeof(nat.Model) == 7 * 4 + 2 * 9 * 4 + 4 + 3 * 8  # hidden_bf16 sits right before the pointers
     # include/az_replay.h
     assert C.sizeof(nat.Replay) == 6 * 8 + 2 * 4
     assert C.sizeof(nat.ReplayState) == 3 * 4

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512) void k_loop(const float* w, int units, int rid
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < units; ++it) {
     if (VARIANT == 0) {
-      az_mlp_unit_loop(u, next, R, acc0, acc1, acc2, ap, ap, lane);
+      az_mlp_unit_loop<false>(u, next, R, acc0, acc1, acc2, ap, ap, lane);
     } else {
       az_f32x4 a[2];
       a[0] = *reinterpret_cast<const az_f32x4*>(ap);

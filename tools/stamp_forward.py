@@ -9,7 +9,7 @@ from bench import make_networks
 dev = torch.device("cuda")
 B = int(os.environ.get("B", 4096))
 pol, val = make_networks("CartPole-v1", 1, dev)
-model = mctx.FusedModel("CartPole-v1", pol, val)
+model = mctx.FusedModel("CartPole-v1", pol, val, hidden_bf16=bool(int(os.environ.get("BF16", "0"))))
 obs = torch.randn(B, 4, device=dev)
 for _ in range(20):
     model.forward(obs)

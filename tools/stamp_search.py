@@ -9,7 +9,7 @@ from bench import make_networks
 dev = torch.device("cuda")
 B, S = int(os.environ.get("B", 4096)), int(os.environ.get("S", 64))
 pol, val = make_networks("CartPole-v1", 1, dev)
-model = mctx.FusedModel("CartPole-v1", pol, val)
+model = mctx.FusedModel("CartPole-v1", pol, val, hidden_bf16=bool(int(os.environ.get("BF16", "0"))))
 env = mctx.envs.make("CartPole-v1")
 st = env.reset(0, batch_size=B)
 rf = mctx.FusedRecurrentFn(model)
