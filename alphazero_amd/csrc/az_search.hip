@@ -247,6 +247,128 @@ AZ_UNROLL_K
   AZ_TREE_EDGE(3);
 }
 
+// The cooperative tree search for two actions and one value atom under the Gumbel rules with the
+// whole tree of a workgroup's lanes in LDS as array-of-structures rows (az_aos21_load): the
+// simulation loop touches no global memory at all.  The tree handed in must be FRESH (as
+// az_tree_init leaves it): only its root is read; every other row starts as the fresh pattern with
+// the fields an expansion would write -- prior logits, their prior probabilities, raw = node
+// value -- already filled in from the evaluation that creates it (node n > 0 is created by
+// simulation n - 1, search.py:97-99; a simulation that ends on the depth limit re-expands an
+// existing node from row sim + 1, which then stays unused).  The evaluation's reward and
+// discount wait in LDS next to the rows.  After the last simulation every thread unpacks its
+// rows into the reference's arrays; rows that were never expanded go back as the fresh pattern.
+static size_t az_aos_lds_bytes(int S) {
+  const int N = S + 1;
+  return ((size_t)AZ_WG_LANES * WaveLds::lane_words(S) + (size_t)AZ_WG_LANES * N * AZ_AOS_WORDS +
+          (size_t)2 * AZ_WG_LANES * N + (size_t)2 * AZ_WG_LANES * S) * 4;
+}
+
+__global__ __launch_bounds__(AZ_TREE_THREADS) void k_search_wave_aos21(SearchCtx c_in, az_tree t, az_injected inj,
+                                                                      unsigned long long* sum_depth) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  AZ_TREE_EDGE(0);
+  const SearchCtx c = az_rule_ctx<1>(c_in);
+  const az_search_desc& d = c.d;
+  constexpr int A = 2;
+  const int S = d.S, N = S + 1;
+  const int tid = threadIdx.x, ln = tid / AZ_POS, h = ln & 1, j = tid & (AZ_POS - 1);
+  const int b = blockIdx.x * AZ_WG_LANES + ln;
+  const bool active = b < d.B;
+  const size_t bb = active ? b : 0;
+  WaveLds s(lds, ln, S);
+  float* const rows = lds + AZ_WG_LANES * WaveLds::lane_words(S) + (size_t)ln * N * AZ_AOS_WORDS;
+  int32_t* const par_base =
+      reinterpret_cast<int32_t*>(lds + AZ_WG_LANES * WaveLds::lane_words(S) + (size_t)AZ_WG_LANES * N * AZ_AOS_WORDS);
+  int32_t* const par = par_base + ln * N;
+  int32_t* const afp = par_base + AZ_WG_LANES * N + ln * N;
+  float* const evrd = reinterpret_cast<float*>(par_base + 2 * AZ_WG_LANES * N) + ln * S * 2;
+  // the rows, one node per thread and turn
+  for (int n = j; n <= S; n += AZ_POS) {
+    FullRow<2, 1> f{};
+    if (n == 0) {
+      const size_t i = bb * N;
+      f.nv = t.node_visits[i];
+      f.raw[0] = t.raw_values[i];
+      f.nval[0] = t.node_values[i];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        f.cidx[a] = t.children_index[i * A + a];
+        f.vis[a] = t.children_visits[i * A + a];
+        f.logits[a] = t.children_prior_logits[i * A + a];
+        f.rew[a] = t.children_rewards[i * A + a];
+        f.disc[a] = t.children_discounts[i * A + a];
+        f.cval[a][0] = t.children_values[i * A + a];
+      }
+      par[0] = t.parents[i];
+      afp[0] = t.action_from_parent[i];
+    } else {
+      const size_t e = bb * S + (n - 1);
+      f.cidx[0] = f.cidx[1] = AZ_UNVISITED;
+      f.logits[0] = inj.prior_logits[e * A];
+      f.logits[1] = inj.prior_logits[e * A + 1];
+      f.raw[0] = f.nval[0] = inj.value[e];
+      evrd[(n - 1) * 2] = inj.reward[e];
+      evrd[(n - 1) * 2 + 1] = inj.discount[e];
+      par[n] = -1;
+      afp[n] = -1;
+    }
+    float pr[2];
+    az_prior_probs<2>(f.logits, A, pr);
+    az_aos21_store(rows + n * AZ_AOS_WORDS, f, pr[0], pr[1]);
+  }
+  az_tree tv{};
+  tv.parents = par_base;
+  tv.action_from_parent = par_base + AZ_WG_LANES * N;
+  Lane<2, 1> l(tv, ln, N, A, 1);
+  if (j == 0) s.selx[0] = az_i32x4{0, 0, 0, 0};
+  __syncthreads();
+  az_wave_init<2, 1, false>(c, l, s, b, j, active, rows);
+  __syncthreads();
+  long long depth_sum = 0;
+  AZ_TREE_EDGE(1);
+  for (int sim = 0; sim < S; ++sim) {
+    AZ_TREE_STAMP(0);
+    const WavePath wp = az_wave_chase_lean(s, h, j, sim, d.max_depth, active);
+    if (j == 0) depth_sum += wp.dep;
+    AZ_TREE_STAMP(2);
+    const float* ev = rows + (sim + 1) * AZ_AOS_WORDS;  // (the row this simulation's evaluation was filled into)
+    az_wave_update<2, 1, false, true, true>(c, l, s, active, h, j, sim, wp, ev + AZ_AOS_LOGITS, ev + AZ_AOS_RAW,
+                                            evrd[sim * 2], evrd[sim * 2 + 1], nullptr, nullptr, rows);
+    AZ_TREE_STAMP(7);
+  }
+  AZ_TREE_EDGE(2);
+  // (a wave writes its own two lanes back: no workgroup barrier, so that the waves that finish
+  // early are done while the slowest one still searches)
+  az_wave_sync();
+  if (active) {
+    for (int n = j; n <= S; n += AZ_POS) {
+      FullRow<2, 1> f;
+      az_aos21_load(rows + n * AZ_AOS_WORDS, f);
+      if (n > 0 && f.nv == 0) {  // never expanded: the fresh pattern (its evaluation was not used)
+        f.logits[0] = f.logits[1] = 0.0f;
+        f.raw[0] = f.nval[0] = 0.0f;
+      }
+      const size_t i = (size_t)b * N + n;
+      t.node_visits[i] = f.nv;
+      t.raw_values[i] = f.raw[0];
+      t.node_values[i] = f.nval[0];
+      t.parents[i] = par[n];
+      t.action_from_parent[i] = afp[n];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        t.children_index[i * A + a] = f.cidx[a];
+        t.children_visits[i * A + a] = f.vis[a];
+        t.children_prior_logits[i * A + a] = f.logits[a];
+        t.children_rewards[i * A + a] = f.rew[a];
+        t.children_discounts[i * A + a] = f.disc[a];
+        t.children_values[i * A + a] = f.cval[a][0];
+      }
+    }
+  }
+  az_add_depth(sum_depth, depth_sum);
+  AZ_TREE_EDGE(3);
+}
+
 // LDS bytes of the cooperative form's own state (cached selections, path, root inputs, keys).
 static size_t az_wave_lds_bytes(const az_search_desc* d) {
   return ((size_t)AZ_WG_LANES * WaveLds::lane_words(d->S) + (size_t)az_key_words(d->S)) * 4;
@@ -270,6 +392,16 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
   if (!inj || !inj->prior_logits || !inj->value || !inj->reward || !inj->discount)
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
   SearchCtx c{*d, *in};
+  if (d->kernel_form == 0 && d->A == 2 && d->K == 1 && d->variant == AZ_VARIANT_GUMBEL && az_rule_of(d) == 1 &&
+      d->S + 1 <= 65535 && az_aos_lds_bytes(d->S) <= 160 * 1024) {
+    const size_t lds = az_aos_lds_bytes(d->S);
+    if (lds > 48 * 1024)
+      AZ_HIP(hipFuncSetAttribute((const void*)k_search_wave_aos21, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_search_wave_aos21<<<dim3((d->B + AZ_WG_LANES - 1) / AZ_WG_LANES), dim3(AZ_TREE_THREADS), lds,
+                          (hipStream_t)stream>>>(c, *t, *inj, reinterpret_cast<unsigned long long*>(sum_depth));
+    AZ_LAUNCH_CHECK();
+    return AZ_OK;
+  }
   if (az_coop_applicable(d, 0, false)) {
     size_t lds = az_wave_lds_bytes(d);
     const int rule = az_rule_of(d);

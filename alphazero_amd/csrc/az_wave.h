@@ -68,6 +68,7 @@ AZ_DEV float az_from_next_lane(float x) {
 // so that the walk covers four levels per LDS round trip.  selx[0] = 0 is what a finished walk
 // keeps reading.  path[t] is the selection word (.x form) of the node at level t.
 typedef __attribute__((ext_vector_type(4))) int az_i32x4;
+typedef __attribute__((ext_vector_type(4))) float az_f32x4_;
 struct WaveLds {
   az_i32x4* selx;     // [S + 2]
   int32_t* path;      // [S + 8]
@@ -233,6 +234,50 @@ AZ_UNROLL_K
     }
 }
 
+// Array-of-structures rows in LDS for two actions and one value atom (the tree-only kernel's
+// form of the staged tree): the 15 words of a node -- plus its prior probabilities,
+// max(tiny, softmax(prior logits)) -- side by side in 64 bytes, so that a thread fetches its row
+// with four 16-byte reads from one address and puts it back with four 16-byte writes, instead of
+// nine reads / up to eleven writes with an address computation each.
+//   w0 node_visits   w1 (child0 + 1) | (child1 + 1) << 16   w2 visits0   w3 visits1
+//   w4 reward0  w5 reward1  w6 discount0  w7 discount1
+//   w8 child value0  w9 child value1  w10 logits0  w11 logits1
+//   w12 prob0  w13 prob1  w14 raw value  w15 node value
+#define AZ_AOS_WORDS 20  // row stride: 16 words + 4 of padding -- rows 64 bytes apart would put the same
+                         // 16-byte part of every row on two groups of four banks (measured: row loads
+                         // 0.56 k -> 0.8 k cycles); with 80 bytes eight consecutive rows cover all 32 banks
+#define AZ_AOS_LOGITS 10
+#define AZ_AOS_PROBS 12
+#define AZ_AOS_RAW 14
+AZ_DEV void az_aos21_load(const float* row, FullRow<2, 1>& f) {
+  const az_i32x4 a = *reinterpret_cast<const az_i32x4*>(row);
+  const az_f32x4_ b = *reinterpret_cast<const az_f32x4_*>(row + 4);
+  const az_f32x4_ c = *reinterpret_cast<const az_f32x4_*>(row + 8);
+  const az_f32x4_ d = *reinterpret_cast<const az_f32x4_*>(row + 12);
+  f.nv = a.x;
+  f.cidx[0] = (a.y & 0xffff) - 1;
+  f.cidx[1] = (int32_t)((uint32_t)a.y >> 16) - 1;
+  f.vis[0] = a.z;
+  f.vis[1] = a.w;
+  f.rew[0] = b.x;
+  f.rew[1] = b.y;
+  f.disc[0] = b.z;
+  f.disc[1] = b.w;
+  f.cval[0][0] = c.x;
+  f.cval[1][0] = c.y;
+  f.logits[0] = c.z;
+  f.logits[1] = c.w;
+  f.raw[0] = d.z;
+  f.nval[0] = d.w;
+}
+AZ_DEV void az_aos21_store(float* row, const FullRow<2, 1>& f, float prob0, float prob1) {
+  const az_i32x4 a = {f.nv, (f.cidx[0] + 1) | ((f.cidx[1] + 1) << 16), f.vis[0], f.vis[1]};
+  *reinterpret_cast<az_i32x4*>(row) = a;
+  *reinterpret_cast<az_f32x4_*>(row + 4) = az_f32x4_{f.rew[0], f.rew[1], f.disc[0], f.disc[1]};
+  *reinterpret_cast<az_f32x4_*>(row + 8) = az_f32x4_{f.cval[0][0], f.cval[1][0], f.logits[0], f.logits[1]};
+  *reinterpret_cast<az_f32x4_*>(row + 12) = az_f32x4_{prob0, prob1, f.raw[0], f.nval[0]};
+}
+
 // The selection inputs of a row held in registers; same arithmetic as az_load_row (a mean over
 // one atom divides by 1.0f, which changes no bit and is left out).
 template <int AMAX, int KMAX>
@@ -339,9 +384,10 @@ AZ_DEV int az_wave_exact_select(const SearchCtx& c, const Lane<AMAX, KMAX>& l, c
 
 // Before the first simulation (all threads of a wave): the root-only inputs into LDS and the
 // selection at the root of the fresh tree.
+// `aos_rows` (or null): the lane's array-of-structures rows; the root's row is read from there.
 template <int AMAX, int KMAX, bool NOISY>
 AZ_DEV void az_wave_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, int b, int j,
-                         bool active) {
+                         bool active, const float* aos_rows = nullptr) {
   const int A = l.A;
   // The lane's row of the considered-visits table, by all of the lane's threads: S words that one
   // thread would fetch one memory latency after the other.
@@ -359,15 +405,26 @@ AZ_DEV void az_wave_init(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const Wa
     s.root_g[a] = c.in.root_gumbel ? c.in.root_gumbel[(size_t)b * A + a] : 0.0f;
     s.root_inv[a] = c.in.invalid_actions ? c.in.invalid_actions[(size_t)b * A + a] : 0.0f;
   }
+  FullRow<AMAX, KMAX> f;
+  if constexpr (AMAX == 2 && KMAX == 1) {
+    if (aos_rows != nullptr)
+      az_aos21_load(aos_rows, f);
+    else
+      az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
+  } else {
+    az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
+  }
   {  // the part of the root's score that no simulation changes (az_score_considered)
-    float mx = l.clog[0];
-    for (int a = 1; a < A; ++a) mx = az_maxf(mx, l.clog[a]);
-    for (int a = 0; a < A; ++a) s.root_glg[a] = s.root_g[a] + (l.clog[a] - mx);
+    float mx = f.logits[0];
+AZ_UNROLL_A
+    for (int a = 1; a < AZ_TRIP_A; ++a)
+      if (a < A) mx = az_maxf(mx, f.logits[a]);
+AZ_UNROLL_A
+    for (int a = 0; a < AZ_TRIP_A; ++a)
+      if (a < A) s.root_glg[a] = s.root_g[a] + (f.logits[a] - mx);
   }
   s.hdr[7] = nc;
-  FullRow<AMAX, KMAX> f;
   NodeRow<AMAX> r;
-  az_load_full_row<AMAX, KMAX>(l, AZ_ROOT, f);
   az_node_row<AMAX, KMAX>(f, A, l.K, r);
   bool ambiguous;
   const int a = az_select_cached<AMAX, NOISY>(c, s.root_cache(c), A, true, r, ambiguous);
@@ -558,7 +615,7 @@ struct WaveRow {
 
 template <int AMAX, int KMAX>
 AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, bool active, int p, int dep, int sim, int32_t e_prev,
-                         int32_t e_mine, WaveRow<AMAX, KMAX>& w) {
+                         int32_t e_mine, WaveRow<AMAX, KMAX>& w, const float* aos_rows = nullptr) {
   const bool mine = active && p <= dep, leaf = p == dep;
   const int kc = p > 0 ? (e_prev & 0xffff) : 1;
   const int on_path = kc - 1;
@@ -566,6 +623,12 @@ AZ_DEV void az_wave_load(const Lane<AMAX, KMAX>& l, bool active, int p, int dep,
   w.node = mine ? (leaf ? fresh : on_path) : AZ_ROOT;
   w.act = mine && !leaf ? (e_mine >> 16) & 0xff : 0;
   w.e_mine_code = e_mine & 0xffff;
+  if constexpr (AMAX == 2 && KMAX == 1) {
+    if (aos_rows != nullptr) {
+      az_aos21_load(aos_rows + w.node * AZ_AOS_WORDS, w.f);
+      return;
+    }
+  }
   az_load_full_row<AMAX, KMAX>(l, w.node, w.f);
 }
 
@@ -775,11 +838,17 @@ AZ_DEV float az_from_next_lane_keep(float x) {
 // turn is.  Threads past the path's end hand the constant through unchanged (-0.0f + 1.0f * x
 // is x for every x), and thread 31 of each lane is pinned so that nothing leaks in from the
 // neighbouring lane of the wave.
-template <int AMAX, int KMAX, bool NOISY, bool FAST_GUMBEL = false>
+// AOS (two actions, one atom, Gumbel rules): the lane's rows are array-of-structures rows at
+// `aos_rows` (az_aos21_load / _store): a thread writes its whole row back once instead of field
+// by field, `l` only provides parents / action_from_parent, and the prior probabilities of node n
+// are words AZ_AOS_PROBS .. of row n (`node_probs` is not used).
+template <int AMAX, int KMAX, bool NOISY, bool FAST_GUMBEL = false, bool AOS = false>
 AZ_DEV void az_wave_update(const SearchCtx& c, const Lane<AMAX, KMAX>& l, const WaveLds& s, bool active,
                            int h, int j, int sim, const WavePath& wp, const float* ev_logits,
                            const float* ev_value, float reward, float discount,
-                           const WaveRow<AMAX, KMAX>* pre = nullptr, float* node_probs = nullptr) {
+                           const WaveRow<AMAX, KMAX>* pre = nullptr, float* node_probs = nullptr,
+                           float* aos_rows = nullptr) {
+  static_assert(!AOS || (AMAX == 2 && KMAX == 1 && FAST_GUMBEL), "array-of-structures rows: 2 actions, 1 atom, Gumbel");
   const int A = l.A, K = l.K;
   const int dep = wp.dep;
   const RootCache rc = s.root_cache(c);
@@ -800,10 +869,10 @@ AZ_UNROLL_K
     if (pre != nullptr && it == 0) {
       w = *pre;
     } else if (it == 0) {
-      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, wp.e_prev, wp.e_mine, w);
+      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, wp.e_prev, wp.e_mine, w, AOS ? aos_rows : nullptr);
     } else {
       const int pp = p <= dep ? p : dep;  // keeps the reads of unused positions inside the path
-      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, s.path[pp - 1], s.path[pp], w);
+      az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, s.path[pp - 1], s.path[pp], w, AOS ? aos_rows : nullptr);
     }
     FullRow<AMAX, KMAX>& f = w.f;
     const int node = w.node, act = w.act;
@@ -819,8 +888,12 @@ AZ_UNROLL_A
           if (!leaf && a == act) f.vis[a] = f.vis[a] + 1;
         }
       // (slot sim + 1 of node_probs holds the values for this simulation's evaluation)
-      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre, rc.table_row,
-                          node_probs != nullptr ? node_probs + (leaf ? sim + 1 : node) * A : nullptr);
+      const float* cached = nullptr;
+      if (AOS)
+        cached = aos_rows + (leaf ? sim + 1 : node) * AZ_AOS_WORDS + AZ_AOS_PROBS;
+      else if (node_probs != nullptr)
+        cached = node_probs + (leaf ? sim + 1 : node) * A;
+      az_gumbel_pre<AMAX>(c.d, A, f.logits, f.vis, gpre, rc.table_row, cached);
       az_gumbel_pre_pin<AMAX>(A, gpre);
     }
     // the edge from this position's node to the next node of the path
@@ -896,17 +969,17 @@ AZ_UNROLL_A
         for (int a = 0; a < AZ_TRIP_A; ++a)
           if (a < A) {
             f.logits[a] = ev_logits[a];
-            l.clog[node * A + a] = f.logits[a];
+            if (!AOS) l.clog[node * A + a] = f.logits[a];
           }
 AZ_UNROLL_K
         for (int k = 0; k < AZ_TRIP_K; ++k)
           if (k < K) {
             f.raw[k] = ev[k];
-            l.raw[(size_t)node * K + k] = ev[k];
+            if (!AOS) l.raw[(size_t)node * K + k] = ev[k];
           }
         l.par[node] = wl.parent;
         l.afp[node] = wl.action;
-        if (FAST_GUMBEL && node_probs != nullptr) {
+        if (FAST_GUMBEL && !AOS && node_probs != nullptr) {
           // an existing node expanded again at the depth cap takes the new evaluation's values
 AZ_UNROLL_A
           for (int a = 0; a < AZ_TRIP_A; ++a)
@@ -923,9 +996,11 @@ AZ_UNROLL_A
               f.rew[a] = reward;
               f.disc[a] = discount;
             }
-          l.cidx[node * A + act] = newn;
-          l.crew[node * A + act] = reward;
-          l.cdisc[node * A + act] = discount;
+          if (!AOS) {
+            l.cidx[node * A + act] = newn;
+            l.crew[node * A + act] = reward;
+            l.cdisc[node * A + act] = discount;
+          }
         }
         int32_t newvis = 0;
 AZ_UNROLL_A
@@ -937,19 +1012,22 @@ AZ_UNROLL_K
             if (!FAST_GUMBEL) f.vis[a] = f.vis[a] + 1;  // (counted ahead of the backup otherwise)
             newvis = f.vis[a];
           }
+        if (!AOS) {
 AZ_UNROLL_K
-        for (int k = 0; k < AZ_TRIP_K; ++k)
-          if (k < K) l.cval[((size_t)node * A + act) * K + k] = child_new[k];
-        l.cvis[node * A + act] = newvis;
+          for (int k = 0; k < AZ_TRIP_K; ++k)
+            if (k < K) l.cval[((size_t)node * A + act) * K + k] = child_new[k];
+          l.cvis[node * A + act] = newvis;
+        }
       }
 AZ_UNROLL_K
       for (int k = 0; k < AZ_TRIP_K; ++k)
         if (k < K) {
           f.nval[k] = nval_new[k];
-          l.nval[(size_t)node * K + k] = nval_new[k];
+          if (!AOS) l.nval[(size_t)node * K + k] = nval_new[k];
         }
       f.nv = f.nv + 1;
-      l.nv[node] = f.nv;
+      if (!AOS) l.nv[node] = f.nv;
+      if constexpr (AOS) az_aos21_store(aos_rows + node * AZ_AOS_WORDS, f, gpre.probs[0], gpre.probs[1]);
       AZ_WAVE_STAMP(6);
       if (!FAST_GUMBEL) {
         // refresh the cached selection of this node

@@ -133,7 +133,9 @@ int az_tree_init(const az_search_desc* d, const az_tree* t, const float* root_lo
 
 /* mctx_dist/_src/search.py:88-112 (the whole fori_loop: simulate :127-187, expand
  * :190-244, backward :247-292) as ONE persistent launch, with the recurrent_fn
- * outputs read from `inj`.  sum_depth (device int64, may be NULL) accumulates the
+ * outputs read from `inj`.  Like search() of the reference, which instantiates its tree
+ * itself (:345-387), this call starts from a fresh tree: `t` must be as az_tree_init leaves it
+ * (some kernels read only its root row and rebuild the rest).  sum_depth (device int64, may be NULL) accumulates the
  * depth of every expanded node, the quantity the bandwidth model is priced on. */
 int az_search_injected(const az_search_desc* d, const az_tree* t, const az_search_inputs* in,
                        const az_injected* inj, int64_t* sum_depth, void* stream);
