@@ -174,7 +174,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
     collected separately under rocprofv3 with the headline workload), or None."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"))).get(
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))).get(
             kernel + "_bytes_per_launch")
     except Exception:
         return None
@@ -183,7 +183,7 @@ def pmc_traffic(kernel):
 def pmc_mfma_util(kernel):
     """Matrix-pipe busy share of `kernel` from the committed SQ counter pass, or None."""
     try:
-        ks = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))["kernels"]
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r03_sq_counters.json")))["kernels"]
         return next((round(v["mfma_util"], 4) for k, v in ks.items() if kernel in k), None)
     except Exception:
         return None
@@ -213,9 +213,9 @@ def tree_kernel_roofline(B, S, A, device, reps=5):
     t = float(np.mean(times))
     alg_bytes = sum_depth * (24 * A + 56) + B * S * (4 * A + 32)
     achieved = alg_bytes / t / 1e9
-    return {"kernel": "k_search_wave_injected", "bound": "hbm", "achieved": round(achieved, 2),
+    return {"kernel": "k_search_wave_aos21", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
-            "traffic": pmc_traffic("k_search_wave_injected"), "ms_per_launch": round(t * 1e3, 4),
+            "traffic": pmc_traffic("k_search_wave_aos21"), "ms_per_launch": round(t * 1e3, 4),
             "mean_depth": round(sum_depth / (B * S), 3),
             "sims_per_s": round(B * S / t, 1)}
 

@@ -34,12 +34,12 @@ def test_algorithmic_work_constants():
 def test_committed_profile_summaries_are_readable():
     t = bench.pmc_traffic("k_search_fused_wave")
     assert t is not None and 1e8 < t < 1e10
-    assert bench.pmc_traffic("k_search_wave_injected") is not None
+    assert bench.pmc_traffic("k_search_wave_aos21") is not None
     u = bench.pmc_mfma_util("k_search_fused_wave")
     assert u is not None and 0.05 < u < 1.0
-    stats = open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")).read()
-    assert "k_search_fused_wave" in stats and "k_search_wave_injected" in stats
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_under_rocprof.log")).read().strip().splitlines()[-1]
+    stats = open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")).read()
+    assert "k_search_fused_wave" in stats and "k_search_wave_aos21" in stats
+    line = open(os.path.join(ROOT, "profiles", "r03_bench_under_rocprof.log")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the profiles committed under profiles/: kernel stats, FETCH_SIZE / WRITE_SIZE and SQ
 # counter passes of the headline bench (each counter pass in a run of its own), then condenses them.
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r02
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r03
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 export TMPDIR=/tmp

@@ -42,7 +42,7 @@ if len(sys.argv) >= 5:
         if "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
             v["hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE_KB_mean"] * 1024 + v["WRITE_SIZE_KB_mean"] * 1024
     for k, v in out.items():
-        for kern in ("k_search_fused_wave", "k_search_wave_injected"):
+        for kern in ("k_search_fused_wave", "k_search_wave_injected", "k_search_wave_aos21"):
             if k.startswith("void " + kern) or k.startswith(kern):
                 res[kern + "_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
     json.dump(res, open(os.path.join(root, f"{tag}_hbm_traffic.json"), "w"), indent=1)
