@@ -49,7 +49,7 @@ class TreePtrs(C.Structure):
 
 
 class SearchInputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("invalid_actions", "root_gumbel", "table", "noise")]
+    _fields_ = [(n, C.c_void_p) for n in ("invalid_actions", "root_gumbel", "table", "noise", "sim_keys")]
 
 
 class Injected(C.Structure):
@@ -107,6 +107,7 @@ SIGNATURES = {
     "az_device_count": (C.c_int, []),
     "az_build_arch": (C.c_char_p, []),
     "az_considered_table": (C.c_int, [_I, _I, _P]),
+    "az_sim_keys": (C.c_int, [_K2, _I, _P]),
     "az_tree_init": (C.c_int, [C.POINTER(SearchDesc), C.POINTER(TreePtrs), _P, _P, _P, _P, _P]),
     "az_search_injected": (C.c_int, [C.POINTER(SearchDesc), C.POINTER(TreePtrs),
                                      C.POINTER(SearchInputs), C.POINTER(Injected), _P, _P]),

@@ -98,6 +98,20 @@ extern "C" int az_considered_table(int32_t max_m, int32_t S, int32_t* table_host
   return AZ_OK;
 }
 
+extern "C" int az_sim_keys(const uint32_t* key, int32_t S, uint32_t* keys_host) {
+  if (!key || S < 1 || !keys_host) return az_fail(AZ_ERR_INVALID, "bad sim_keys arguments");
+  // the same two splits per simulation as az_wave_sim_keys (az_wave.h), on the host
+  uint32_t r0 = key[0], r1 = key[1];
+  for (int i = 0; i < S; ++i) {
+    az_key_split(r0, r1, 1u, &keys_host[2 * i], &keys_host[2 * i + 1]);
+    uint32_t n0, n1;
+    az_key_split(r0, r1, 0u, &n0, &n1);
+    r0 = n0;
+    r1 = n1;
+  }
+  return AZ_OK;
+}
+
 // ---------------------------------------------------------------------------
 // policy prologues / epilogues: one thread per lane, run-time A
 AZ_DEV void az_softmax_rt(const float* x, int A, float* out) {
@@ -177,13 +191,18 @@ extern "C" int az_root_muzero(int32_t B, int32_t A, const float* prior_logits,
   return AZ_OK;
 }
 
+// AZ_SAMPLE_T threads per lane share the lane's draws (sample smp belongs to thread smp %
+// AZ_SAMPLE_T; every draw has its own counter, and the counts are small integers, so the order
+// in which they are added up changes nothing).
+#define AZ_SAMPLE_T 16
 __global__ void k_root_sampled(int B, int A, const float* __restrict__ prior_logits,
                                const float* __restrict__ dirichlet, float fraction,
                                const float* __restrict__ invalid, int num_samples, float temperature,
                                float exponent, const float* __restrict__ counts_in, uint32_t key0,
                                uint32_t key1, float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int g = blockIdx.x * (blockDim.x / AZ_SAMPLE_T) + threadIdx.x / AZ_SAMPLE_T;
+  const int t = threadIdx.x % AZ_SAMPLE_T;
+  const int b = g < B ? g : B - 1;  // (the threads past the last lane repeat it and write nothing)
   float L[AZ_MAX_ACTIONS], sd[AZ_MAX_ACTIONS], counts[AZ_MAX_ACTIONS], prior[AZ_MAX_ACTIONS];
   az_noisy_root_logits(prior_logits + (size_t)b * A, dirichlet + (size_t)b * A, fraction,
                        invalid ? invalid + (size_t)b * A : nullptr, A, L);
@@ -193,7 +212,7 @@ __global__ void k_root_sampled(int B, int A, const float* __restrict__ prior_log
     for (int a = 0; a < A; ++a) counts[a] = counts_in[(size_t)b * A + a];
   } else {
     for (int a = 0; a < A; ++a) counts[a] = 0.0f;
-    for (int smp = 0; smp < num_samples; ++smp) {
+    for (int smp = t; smp < num_samples; smp += AZ_SAMPLE_T) {
       int best = 0;
       float bv = 0.0f;
       for (int a = 0; a < A; ++a) {
@@ -207,7 +226,10 @@ __global__ void k_root_sampled(int B, int A, const float* __restrict__ prior_log
       for (int a = 0; a < A; ++a)
         if (a == best) counts[a] += 1.0f;
     }
+    for (int a = 0; a < A; ++a)
+      for (int o = AZ_SAMPLE_T / 2; o > 0; o >>= 1) counts[a] += __shfl_xor(counts[a], o, AZ_SAMPLE_T);
   }
+  if (g >= B || t != 0) return;
   az_softmax_rt(L, A, prior);
   for (int a = 0; a < A; ++a)
     out[(size_t)b * A + a] = (counts[a] / (float)num_samples) * az_powf(prior[a], exponent);
@@ -221,7 +243,8 @@ extern "C" int az_root_sampled(int32_t B, int32_t A, const float* prior_logits,
   if (B < 1 || A < 1 || A > AZ_MAX_ACTIONS || !prior_logits || !dirichlet || !out_probs ||
       num_samples < 1 || (!counts_in && !key_host))
     return az_fail(AZ_ERR_INVALID, "bad root_sampled arguments");
-  k_root_sampled<<<dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+  constexpr int kLanesPerBlock = 256 / AZ_SAMPLE_T;
+  k_root_sampled<<<dim3((B + kLanesPerBlock - 1) / kLanesPerBlock), dim3(256), 0, (hipStream_t)stream>>>(
       B, A, prior_logits, dirichlet, dirichlet_fraction, invalid, num_samples, temperature,
       exponent, counts_in, key_host ? key_host[0] : 0u, key_host ? key_host[1] : 0u, out_probs);
   AZ_LAUNCH_CHECK();

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   float* const emb_base = reinterpret_cast<float*>(sim_keys + az_key_words(S));
   float* emb = emb_in_lds ? emb_base + ln * (S + 1) * 5 : nullptr;
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
-  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
+  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x, c.in.sim_keys);
   az_stage_inputs(md, s, tid, blockDim.x);
   if (j == 0) ws.selx[0] = az_i32x4{0, 0, 0, 0};
   {
@@ -674,6 +674,15 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
 extern "C" int az_debug_read_stamps(long long* host_out) {
   AZ_HIP(hipDeviceSynchronize());
   AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_stamps), sizeof(long long) * 8 * 64));
+  return AZ_OK;
+}
+extern "C" int az_debug_read_flag_counts(unsigned long long* host_out, int reset) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_dbg_flag_counts), sizeof(unsigned long long) * 4));
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    AZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(az_dbg_flag_counts), z, sizeof(z)));
+  }
   return AZ_OK;
 }
 extern "C" int az_debug_read_sim_stamps(long long* host_out) {

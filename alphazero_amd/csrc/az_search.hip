@@ -195,7 +195,7 @@ AZ_UNROLL_A
   const az_tree tv = tree_in_lds ? tl.view() : t;
   Lane<AMAX, KMAX> l(tv, tree_in_lds ? ln : (active ? b : 0), S + 1, A, K);
   const bool need_keys = NOISY && d.variant != AZ_VARIANT_GUMBEL && d.noise_mode == AZ_NOISE_THREEFRY;
-  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x);
+  if (need_keys) az_wave_sim_keys(d, sim_keys, tid, blockDim.x, c.in.sim_keys);
   if (j == 0) s.selx[0] = az_i32x4{0, 0, 0, 0};
   __syncthreads();
   az_wave_init<AMAX, KMAX, NOISY>(c, l, s, b, j, active);

@@ -47,6 +47,17 @@
   } while (0)
 #endif
 
+#ifdef AZ_STAMP
+// Diagnostic build only: [0] walks repeated level by level, [1] exact selections, [2] key splits
+// of those, [3] walks in all.
+static __device__ unsigned long long az_dbg_flag_counts[4];
+#define AZ_DBG_COUNT(i, n) atomicAdd(&az_dbg_flag_counts[i], (unsigned long long)(n))
+#else
+#define AZ_DBG_COUNT(i, n) \
+  do {                     \
+  } while (0)
+#endif
+
 // Compiler-level ordering point between LDS / memory accesses of different threads of ONE wave
 // (the hardware already executes a wave's memory instructions in program order).
 AZ_DEV void az_wave_sync() {
@@ -367,6 +378,9 @@ AZ_DEV int az_wave_exact_select(const SearchCtx& c, const Lane<AMAX, KMAX>& l, c
   const int A = l.A;
   NodeRow<AMAX> r;
   az_load_row<AMAX, KMAX>(l, node, r);
+  AZ_DBG_COUNT(1, 1);
+  if (c.d.noise_mode == AZ_NOISE_THREEFRY)
+    AZ_DBG_COUNT(2, depth - key_depth);
   if (c.d.noise_mode == AZ_NOISE_THREEFRY)
     for (; key_depth < depth; ++key_depth) {
       uint32_t n0, n1;
@@ -438,7 +452,14 @@ AZ_UNROLL_A
 // The simulate keys of all S simulations into `sim_keys` ([S][2] words of LDS): the rng chain
 // rng, simulate_key, expand_key = split(rng, 3) (search.py:90) is sequential, so one thread walks
 // it and the others derive their simulation's key from it.  Workgroup-wide call (barriers).
-AZ_DEV void az_wave_sim_keys(const az_search_desc& d, uint32_t* sim_keys, int tid, int nthreads) {
+// `given` (or null): the finished keys, worked out by the host (az_sim_keys); copied as they are.
+AZ_DEV void az_wave_sim_keys(const az_search_desc& d, uint32_t* sim_keys, int tid, int nthreads,
+                             const uint32_t* given = nullptr) {
+  if (given != nullptr) {
+    for (int i = tid; i < 2 * d.S; i += nthreads) sim_keys[i] = given[i];
+    __syncthreads();
+    return;
+  }
   if (tid == 0) {
     uint32_t r0 = d.key[0], r1 = d.key[1];
     for (int i = 0; i < d.S; ++i) {
@@ -583,7 +604,9 @@ AZ_DEV WavePath az_wave_chase_flagged(const SearchCtx& c, const Lane<AMAX, KMAX>
     const int p = base + j;
     flagged = flagged || (active && p < w.dep && (s.path[p] & AZ_SEL_AMBIG) != 0);
   }
+  if (j == 0 && active) AZ_DBG_COUNT(3, 1);
   if (__builtin_amdgcn_ballot_w64(flagged) == 0) return w;
+  if (j == 0 && active) AZ_DBG_COUNT(0, 1);
   return az_wave_chase_noisy<AMAX, KMAX>(c, l, s, b, h, j, sim, max_depth, active, sim_keys);
 }
 

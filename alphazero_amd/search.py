@@ -12,6 +12,7 @@ drives one of three device paths, all writing the same Tree arrays:
 """
 import ctypes as C
 import dataclasses
+import numpy as np
 
 import torch
 
@@ -114,8 +115,9 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
     [B, num_simulations, depth, A] (or "zero"); `stats`, a dict, receives
     `sum_depth`, a device int64 with the summed depth of all expanded nodes; on input
     `stats['kernel_form'] = 'literal'` selects the one-thread-per-lane kernels (used to
-    cross-check the two kernel forms) and `stats['record_events']` brackets the search
-    launch with HIP events.
+    cross-check the two kernel forms), `stats['sim_keys'] = 'device'` leaves the
+    per-simulation keys to the kernels (cross-check of the host-derived ones) and
+    `stats['record_events']` brackets the search launch with HIP events.
     `loop_fn` is accepted for signature compatibility and ignored.
     """
     del loop_fn
@@ -161,6 +163,15 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
         inputs.root_gumbel = nat.ptr(gumbel)
         inputs.table = nat.ptr(table)
         keep += [gumbel, table]
+
+    if d.noise_mode == nat.NOISE_THREEFRY and not (stats is not None and stats.get("sim_keys") == "device"):
+        # the per-simulation keys (search.py:90) form a sequential chain: one CPU core walks it in
+        # microseconds, one GPU thread per workgroup would take tens of them
+        host_keys = np.empty((S, 2), dtype=np.uint32)
+        nat.check(lib.az_sim_keys(_key_words((int(d.key[0]), int(d.key[1]))), S, host_keys.ctypes.data_as(C.c_void_p)))
+        sim_keys = torch.from_numpy(host_keys.view(np.int32)).to(dev)
+        inputs.sim_keys = nat.ptr(sim_keys)
+        keep.append(sim_keys)
 
     arrays = tree_lib.allocate(B, S, A, K, dev, scalar_values=scalar_values)
     tp = nat.TreePtrs()

@@ -79,6 +79,10 @@ typedef struct az_search_inputs {
   const float* root_gumbel;     /* [B,A] GumbelMuZeroExtraData.root_gumbel, gumbel variant */
   const int32_t* table;         /* [(m+1),S] from az_considered_table, gumbel variant      */
   const float* noise;           /* [B,S,Dn,A] uniform draws when noise_mode = INJECTED     */
+  const uint32_t* sim_keys;     /* [S,2] the output of az_sim_keys copied to the device, or NULL: the
+                                 * cooperative kernels then derive the keys themselves, one thread
+                                 * of every workgroup walking the sequential chain (read with
+                                 * noise_mode = THREEFRY only)                                */
 } az_search_inputs;
 
 /* Evaluations injected per (lane, simulation) in place of a recurrent_fn. */
@@ -124,6 +128,12 @@ const char* az_build_arch(void);
 /* mctx_dist/_src/seq_halving.py:73-88 get_table_of_considered_visits: fills the HOST
  * array table[(max_m+1) * S]. */
 int az_considered_table(int32_t max_m, int32_t S, int32_t* table_host);
+
+/* mctx_dist/_src/search.py:90 `rng, simulate_key, expand_key = split(rng, 3)` for all S
+ * simulations of a search with key `key`: fills the HOST array keys_host[S][2] with every
+ * simulation's simulate key.  The chain is sequential in the simulation index, which suits one
+ * CPU core far better than one GPU thread; az_search_inputs.sim_keys takes a device copy. */
+int az_sim_keys(const uint32_t key[2], int32_t S, uint32_t* keys_host);
 
 /* mctx_dist/_src/search.py:345-387 instantiate_tree_from_root.  root_state [B,4] /
  * root_time [B] may be NULL when the tree carries no native embedding. */

@@ -429,17 +429,29 @@ def test_three_action_environments_full_size_properties(hip, env_id, variant):
 
 
 # ---------------------------------------------------------------- device RNG paths
-def test_default_rng_paths_vs_oracle(hip, oracle):
-    """Without injected noise the device threefry streams equal the C checker's."""
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("sim_keys", ["host", "device"])
+def test_default_rng_paths_vs_oracle(hip, oracle, ties, sim_keys):
+    """Without injected noise the device threefry streams equal the C checker's, with the
+    per-simulation keys worked out by the host (az_sim_keys) and by the kernel itself.
+    ties: equal priors and evaluations everywhere, so that the visit's own noise decides every
+    selection and the keys are actually used."""
     import alphazero_amd as mctx
     from alphazero_amd import prng
     case = runners.synthetic_case("muzero", B=32, S=16, A=3, K=1, seed=31)
+    if ties:
+        case["prior_logits"][:] = 0.0
+        case["dirichlet"][:] = 1.0 / 3.0
+        case["evals"]["prior_logits"][:] = 0.0
+        case["evals"]["value"][:] = 0.5
+        case["value"][:] = 0.5
     ev = {k: hip.dev(x) for k, x in case["evals"].items()}
     rf = mctx.InjectedRecurrentFn(ev["prior_logits"], ev["value"], ev["reward"], ev["discount"])
     root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"]),
                              embedding=None)
     key = (7, 11)
-    out = mctx.muzero_policy((), key, root, rf, 16, dirichlet_noise=hip.dev(case["dirichlet"]))
+    stats = {"sim_keys": sim_keys}
+    out = mctx.muzero_policy((), key, root, rf, 16, dirichlet_noise=hip.dev(case["dirichlet"]), stats=stats)
     torch.cuda.synchronize()
     rng_key, _, search_key = prng.split(key, 3)
     cfg = oracle.make_cfg(32, 16, 3, 1, variant="muzero", noise_mode="threefry", key=search_key)

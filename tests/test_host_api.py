@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     # sizes computed by hand from include/az_mcts.h
     assert C.sizeof(nat.SearchDesc) == 22 * 4
     assert C.sizeof(nat.TreePtrs) == 13 * 8
-    assert C.sizeof(nat.SearchInputs) == 4 * 8
+    assert C.sizeof(nat.SearchInputs) == 5 * 8
     assert C.sizeof(nat.Injected) == 4 * 8
     assert C.sizeof(nat.MlpParams) == 4 + 9 * 4 + 8 * 8 * 2
     assert C.sizeof(nat.Model) == 7 * 4 + 2 * 9 * 4 + 4 + 3 * 8  # hidden_bf16 sits right before the pointers
@@ -161,3 +161,19 @@ def test_golden_fixture_matches_checker():
         for f in make_golden.FIELDS:
             assert np.array_equal(res[f], g[f"{name}/{f}"]), (name, f)
         assert res["sum_depth"] == int(g[f"{name}/sum_depth"])
+
+
+def test_sim_keys_follow_the_search_loop_chain():
+    """az_sim_keys against the chain of search.py:90 written with the host threefry:
+    rng, simulate_key, expand_key = split(rng, 3) per simulation."""
+    import ctypes as C
+    import numpy as np
+    lib = nat.lib()
+    S, key = 37, (0x12345678, 0x9abcdef0)
+    out = np.zeros((S, 2), np.uint32)
+    nat.check(lib.az_sim_keys((C.c_uint32 * 2)(*key), S, out.ctypes.data_as(C.c_void_p)))
+    rng = key
+    for i in range(S):
+        rng, simulate_key, _ = prng.split(rng, 3)
+        assert tuple(int(x) for x in out[i]) == simulate_key, i
+    assert lib.az_sim_keys(None, S, out.ctypes.data_as(C.c_void_p)) == -1

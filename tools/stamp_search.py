@@ -16,8 +16,12 @@ rf = mctx.FusedRecurrentFn(model)
 logits, value = model.forward(st.obs)
 root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
 for _ in range(3):
-    if os.environ.get("VARIANT", "gumbel") == "sampled":
-        mctx.sampled_muzero_policy((), 0, root, rf, S, num_samples=100)
+    variant = os.environ.get("VARIANT", "gumbel")
+    noise = {"tiebreak_noise": "zero"} if variant.endswith("_zero") else {}
+    if variant.startswith("sampled"):
+        mctx.sampled_muzero_policy((), 0, root, rf, S, num_samples=100, **noise)
+    elif variant.startswith("muzero"):
+        mctx.muzero_policy((), 0, root, rf, S, **noise)
     else:
         mctx.gumbel_muzero_policy((), 0, root, rf, S)
 torch.cuda.synchronize()
