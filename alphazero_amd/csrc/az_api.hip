@@ -38,8 +38,11 @@ int az_check_desc(const az_search_desc* d, const az_tree* t) {
   if (d->qtransform < 0 || d->qtransform > 2)
     return az_fail(AZ_ERR_INVALID, "bad qtransform %d", d->qtransform);
   if (d->max_depth < 1) return az_fail(AZ_ERR_INVALID, "max_depth=%d must be >= 1", d->max_depth);
-  if ((int64_t)d->B * (d->S + 1) * d->A * d->K > (int64_t)1 << 40)
-    return az_fail(AZ_ERR_UNSUPPORTED, "tree too large");
+  // (the kernels address a lane's rows by 32-bit byte offsets: no array may reach 4 GiB; the
+  // widest ones are children_values [B,N,A,K] and the [B,N,4] environment states)
+  const int64_t widest = (int64_t)d->A * d->K > 4 ? (int64_t)d->A * d->K : 4;
+  if ((int64_t)d->B * (d->S + 1) * widest * 4 >= (int64_t)1 << 32)
+    return az_fail(AZ_ERR_UNSUPPORTED, "tree too large: an array of B*(S+1)*%lld words reaches 4 GiB", (long long)widest);
   if (!t->node_visits || !t->raw_values || !t->node_values || !t->parents ||
       !t->action_from_parent || !t->children_index || !t->children_prior_logits ||
       !t->children_visits || !t->children_rewards || !t->children_discounts || !t->children_values)

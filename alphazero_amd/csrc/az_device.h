@@ -30,29 +30,46 @@ constexpr int az_uf(int n) { return n <= 16 ? n : 1; }
 #define AZ_UNROLL_K _Pragma("unroll az_uf(KMAX)")
 #define AZ_TRIP_K (KMAX <= 16 ? KMAX : K)
 
+// One lane's part of one of the tree's arrays: the array itself -- the same address in every
+// thread, which stays in scalar registers -- and the lane's BYTE offset into it, 32 bits that all
+// arrays of one shape share, instead of a 64-bit address per array in every thread (thirteen
+// arrays: 26 vector registers).  The host refuses trees whose arrays reach 4 GiB
+// (az_check_desc).
+template <typename T>
+struct LaneArr {
+  T* base;
+  uint32_t off;
+  AZ_DEV T* at(uint32_t i) const {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (off + i * (uint32_t)sizeof(T)));
+  }
+  AZ_DEV T& operator[](size_t i) const { return *at((uint32_t)i); }
+  AZ_DEV T* operator+(size_t i) const { return at((uint32_t)i); }
+  AZ_DEV explicit operator bool() const { return base != nullptr; }
+};
+
 template <int AMAX, int KMAX>
 struct Lane {
   int A, K;
-  int32_t *nv, *par, *afp, *cidx, *cvis;
-  float *raw, *nval, *clog, *crew, *cdisc, *cval;
-  float* es;
-  int32_t* et;
+  LaneArr<int32_t> nv, par, afp, cidx, cvis;
+  LaneArr<float> raw, nval, clog, crew, cdisc, cval;
+  LaneArr<float> es;
+  LaneArr<int32_t> et;
 
   AZ_DEV Lane(const az_tree& t, int b, int N, int A_, int K_) : A(A_), K(K_) {
-    size_t bn = (size_t)b * N;
-    nv = t.node_visits + bn;
-    par = t.parents + bn;
-    afp = t.action_from_parent + bn;
-    cidx = t.children_index + bn * A;
-    cvis = t.children_visits + bn * A;
-    raw = t.raw_values + bn * K;
-    nval = t.node_values + bn * K;
-    clog = t.children_prior_logits + bn * A;
-    crew = t.children_rewards + bn * A;
-    cdisc = t.children_discounts + bn * A;
-    cval = t.children_values + bn * A * K;
-    es = t.emb_state ? t.emb_state + bn * 4 : nullptr;
-    et = t.emb_time ? t.emb_time + bn : nullptr;
+    const uint32_t bn = (uint32_t)b * (uint32_t)N * 4u;  // bytes of the [B, N] arrays ahead of the lane
+    nv = {t.node_visits, bn};
+    par = {t.parents, bn};
+    afp = {t.action_from_parent, bn};
+    cidx = {t.children_index, bn * A};
+    cvis = {t.children_visits, bn * A};
+    raw = {t.raw_values, bn * K};
+    nval = {t.node_values, bn * K};
+    clog = {t.children_prior_logits, bn * A};
+    crew = {t.children_rewards, bn * A};
+    cdisc = {t.children_discounts, bn * A};
+    cval = {t.children_values, bn * A * K};
+    es = {t.emb_state, bn * 4};
+    et = {t.emb_time, bn};
   }
 };
 

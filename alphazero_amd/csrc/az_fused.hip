@@ -464,7 +464,10 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
   for (int sim = 0; sim < S; ++sim) {
     AZ_SIM_STAMP(0);
     MlpRegs regs;
-    constexpr bool kPrefetch = sizeof(WaveRow<AMAX, KMAX>) <= 34 * 4;
+#ifndef AZ_PREFETCH_MAX_WORDS
+#define AZ_PREFETCH_MAX_WORDS 34
+#endif
+    constexpr bool kPrefetch = sizeof(WaveRow<AMAX, KMAX>) <= AZ_PREFETCH_MAX_WORDS * 4;
     WaveRow<AMAX, KMAX> P0;
     WavePath wp;
     {

@@ -32,9 +32,12 @@ bool az_coop_applicable(const az_search_desc* d, size_t extra_lds_bytes, bool bo
 template <typename F>
 static int az_dispatch_ak(int A, int K, F&& f) {
 #ifdef AZ_NARROW_BUILD
-  // diagnostic builds only: one instantiation (A <= 2, K == 1) to keep compile times short
-  if (A <= 2 && K == 1) return f.template operator()<2, 1>();
-  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A <= 2 and K == 1 only");
+  // diagnostic builds only: one instantiation (A <= AZ_NARROW_A, K == 1) to keep compile times short
+#ifndef AZ_NARROW_A
+#define AZ_NARROW_A 2
+#endif
+  if (A <= AZ_NARROW_A && K == 1) return f.template operator()<AZ_NARROW_A, 1>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A <= AZ_NARROW_A and K == 1 only");
 #else
 #define AZ_K_CASES(AM)                                  \
   if (K == 1) return f.template operator()<AM, 1>();    \
@@ -56,8 +59,8 @@ static int az_dispatch_ak(int A, int K, F&& f) {
 template <typename F>
 static int az_dispatch_coop(int A, int K, F&& f) {
 #ifdef AZ_NARROW_BUILD
-  if (A == 2 && K == 1) return f.template operator()<2, 1, true>();
-  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A == 2 and K == 1 only");
+  if (A == AZ_NARROW_A && K == 1) return f.template operator()<AZ_NARROW_A, 1, true>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A == AZ_NARROW_A and K == 1 only");
 #else
   if (K == 1) {
     if (A == 2) return f.template operator()<2, 1, true>();

@@ -898,7 +898,12 @@ AZ_UNROLL_K
       az_wave_load<AMAX, KMAX>(l, active, p, dep, sim, s.path[pp - 1], s.path[pp], w, AOS ? aos_rows : nullptr);
     }
     FullRow<AMAX, KMAX>& f = w.f;
-    const int node = w.node, act = w.act;
+    int node = w.node;
+    const int act = w.act;
+    // A row loaded ahead of the evaluation: the addresses of its words were worked out there, and
+    // the ones written here are the same -- left visible, they are kept in registers (or spilled)
+    // across the networks instead of being worked out again.
+    if (pre != nullptr) asm volatile("" : "+v"(node));
     AZ_WAVE_STAMP(3);
     // What the refreshed selection needs besides the backup's result: the evaluated node takes the
     // new prior logits, the path's nodes one more visit of the action the path took.

@@ -8,6 +8,8 @@ CASES = [("gumbel", "CartPole-v1", 4096, 64), ("muzero", "CartPole-v1", 64, 32),
          ("muzero", "CartPole-v1", 4096, 64), ("sampled", "CartPole-v1", 4096, 64),
          ("gumbel", "Acrobot-v1", 8192, 64), ("gumbel", "MountainCar-v0", 8192, 64),
          ("gumbel", "CartPole-v1", 16384, 256)]
+if os.environ.get("ONLY"):  # e.g. ONLY=Acrobot
+    CASES = [c for c in CASES if os.environ["ONLY"] in c[1]]
 for variant, env_id, B, S in CASES:
     pol, val = make_networks(env_id, 1, dev)
     model = mctx.FusedModel(env_id, pol, val)

@@ -2,15 +2,16 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alphazero_amd import _native as nat
-nat.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libaz_mcts_stamp.so")
+nat.LIB_PATH = os.environ.get("AZ_MCTS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libaz_mcts_stamp.so")
 import numpy as np, torch
 import alphazero_amd as mctx
 from bench import make_networks
 dev = torch.device("cuda")
 B, S = int(os.environ.get("B", 4096)), int(os.environ.get("S", 64))
-pol, val = make_networks("CartPole-v1", 1, dev)
-model = mctx.FusedModel("CartPole-v1", pol, val, hidden_bf16=bool(int(os.environ.get("BF16", "0"))))
-env = mctx.envs.make("CartPole-v1")
+ENV = os.environ.get("ENV", "CartPole-v1")
+pol, val = make_networks(ENV, 1, dev)
+model = mctx.FusedModel(ENV, pol, val, hidden_bf16=bool(int(os.environ.get("BF16", "0"))))
+env = mctx.envs.make(ENV)
 st = env.reset(0, batch_size=B)
 rf = mctx.FusedRecurrentFn(model)
 logits, value = model.forward(st.obs)
