@@ -9,9 +9,11 @@ call does, and it raises if the library is missing (there is no fallback path).
 from .action_selection import (GumbelMuZeroExtraData, gumbel_muzero_interior_action_selection,
                                gumbel_muzero_root_action_selection, muzero_action_selection,
                                sampled_muzero_action_selection)
-from .base import PolicyOutput, RecurrentFnOutput, RootFnOutput
+from .base import (ChanceRecurrentFnOutput, DecisionRecurrentFnOutput, PolicyOutput, RecurrentFnOutput,
+                   RootFnOutput, StochasticRecurrentState)
 from .networks import FusedModel, FusedRecurrentFn, init_mlp
-from .policies import actor_post, gumbel_muzero_policy, muzero_policy, sampled_muzero_policy
+from .policies import (actor_post, gumbel_muzero_policy, muzero_policy, sampled_muzero_policy,
+                       stochastic_muzero_policy)
 from .qtransforms import (qtransform_by_min_max, qtransform_by_parent_and_siblings,
                           qtransform_completed_by_mix_value)
 from .search import InjectedRecurrentFn, search
@@ -31,4 +33,6 @@ __all__ = [
     "muzero_action_selection", "muzero_policy", "qtransform_by_min_max",
     "qtransform_by_parent_and_siblings", "qtransform_completed_by_mix_value",
     "sampled_muzero_action_selection", "sampled_muzero_policy", "search",
+    "ChanceRecurrentFnOutput", "DecisionRecurrentFnOutput", "StochasticRecurrentState",
+    "stochastic_muzero_policy",
 ]

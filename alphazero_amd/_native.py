@@ -19,6 +19,7 @@ VARIANT_MUZERO, VARIANT_SAMPLED, VARIANT_GUMBEL = 0, 1, 2
 QT_PARENT_SIBLINGS, QT_COMPLETED_MIX, QT_MIN_MAX = 0, 1, 2
 ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_ACROBOT = 1, 2, 3
 NOISE_THREEFRY, NOISE_INJECTED, NOISE_ZERO = 0, 1, 2
+VARIANT_STOCHASTIC = 3
 
 
 class NativeLibraryError(RuntimeError):
@@ -35,7 +36,7 @@ class SearchDesc(C.Structure):
         ("min_value", C.c_float), ("max_value", C.c_float),
         ("max_num_considered", C.c_int32), ("noise_mode", C.c_int32),
         ("noise_depth", C.c_int32), ("key", C.c_uint32 * 2),
-        ("kernel_form", C.c_int32),
+        ("kernel_form", C.c_int32), ("num_decision_actions", C.c_int32),
     ]
 
 
@@ -49,7 +50,7 @@ class TreePtrs(C.Structure):
 
 
 class SearchInputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("invalid_actions", "root_gumbel", "table", "noise", "sim_keys")]
+    _fields_ = [(n, C.c_void_p) for n in ("invalid_actions", "root_gumbel", "table", "noise", "is_decision", "sim_keys")]
 
 
 class Injected(C.Structure):

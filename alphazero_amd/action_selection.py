@@ -42,6 +42,14 @@ def gumbel_muzero_interior_action_selection(rng_key=None, tree=None, node_index=
     raise NotImplementedError(_MSG)
 
 
+def stochastic_muzero_action_selection(rng_key=None, tree=None, node_index=None, depth=None, *,
+                                       decision_node_selection_fn=None, num_actions=None):
+    """mctx_dist/_src/policies.py:676-708 (_make_stochastic_action_selection_fn): decision nodes
+    select with `decision_node_selection_fn` (a muzero_action_selection partial) over the first
+    `num_actions` columns, chance nodes with argmax(softmax(chance logits) / (visits + 1))."""
+    raise NotImplementedError(_MSG)
+
+
 @dataclasses.dataclass(frozen=True)
 class GumbelMuZeroExtraData:
     """mctx_dist/_src/action_selection.py:138-141"""
@@ -65,6 +73,16 @@ def resolve(root_fn, interior_fn, desc, num_simulations):
         desc.max_num_considered = int(m)
         q_root = rkw.get("qtransform", qt.qtransform_completed_by_mix_value)
         q_int = ikw.get("qtransform", qt.qtransform_completed_by_mix_value)
+    elif rf is inf and rf is stochastic_muzero_action_selection:
+        dec, dkw = qt.unwrap_partial(ikw.get("decision_node_selection_fn"))
+        if dec is not muzero_action_selection or rkw != ikw:
+            raise NotImplementedError("stochastic selection: decision nodes select with a "
+                                      "muzero_action_selection partial, the same at the root")
+        desc.variant = nat.VARIANT_STOCHASTIC
+        desc.num_decision_actions = int(ikw["num_actions"])
+        desc.pb_c_init = float(dkw.get("pb_c_init", 1.25))
+        desc.pb_c_base = float(dkw.get("pb_c_base", 19652.0))
+        q_root = q_int = dkw.get("qtransform", qt.qtransform_by_parent_and_siblings)
     elif rf is inf and rf in (muzero_action_selection, sampled_muzero_action_selection):
         desc.variant = (nat.VARIANT_MUZERO if rf is muzero_action_selection
                         else nat.VARIANT_SAMPLED)

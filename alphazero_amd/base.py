@@ -40,6 +40,31 @@ class PolicyOutput(_Replaceable, Generic[T]):
     search_tree: Any
 
 
+@dataclasses.dataclass(frozen=True)
+class DecisionRecurrentFnOutput(_Replaceable):
+    """mctx_dist/_src/base.py:103-118: chance_logits [B,C], afterstate_value [B]."""
+    chance_logits: Any
+    afterstate_value: Any
+
+
+@dataclasses.dataclass(frozen=True)
+class ChanceRecurrentFnOutput(_Replaceable):
+    """mctx_dist/_src/base.py:121-139: action_logits [B,A], value [B], reward [B], discount [B]."""
+    action_logits: Any
+    value: Any
+    reward: Any
+    discount: Any
+
+
+@dataclasses.dataclass(frozen=True)
+class StochasticRecurrentState(_Replaceable):
+    """mctx_dist/_src/base.py:142-161: the embedding of a Stochastic MuZero node; a decision
+    node's afterstate_embedding and a chance node's state_embedding are dummies."""
+    state_embedding: Any
+    afterstate_embedding: Any
+    is_decision_node: Any  # [B] bool
+
+
 Params = Any
 RecurrentState = Any
 RecurrentFn = Callable[[Params, Any, Any, RecurrentState], Tuple[RecurrentFnOutput, RecurrentState]]

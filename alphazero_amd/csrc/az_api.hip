@@ -34,7 +34,9 @@ int az_check_desc(const az_search_desc* d, const az_tree* t) {
     return az_fail(AZ_ERR_UNSUPPORTED, "num_actions=%d outside [1,%d]", d->A, AZ_MAX_ACTIONS);
   if (d->K < 1 || d->K > AZ_MAX_ATOMS)
     return az_fail(AZ_ERR_UNSUPPORTED, "num_atoms=%d outside [1,%d]", d->K, AZ_MAX_ATOMS);
-  if (d->variant < 0 || d->variant > 2) return az_fail(AZ_ERR_INVALID, "bad variant %d", d->variant);
+  if (d->variant < 0 || d->variant > 3) return az_fail(AZ_ERR_INVALID, "bad variant %d", d->variant);
+  if (d->variant == AZ_VARIANT_STOCHASTIC && (d->num_decision_actions < 1 || d->num_decision_actions >= d->A))
+    return az_fail(AZ_ERR_INVALID, "num_decision_actions=%d must lie in [1, A=%d)", d->num_decision_actions, d->A);
   if (d->qtransform < 0 || d->qtransform > 2)
     return az_fail(AZ_ERR_INVALID, "bad qtransform %d", d->qtransform);
   if (d->max_depth < 1) return az_fail(AZ_ERR_INVALID, "max_depth=%d must be >= 1", d->max_depth);
@@ -52,6 +54,8 @@ int az_check_desc(const az_search_desc* d, const az_tree* t) {
 
 int az_check_inputs(const az_search_desc* d, const az_search_inputs* in) {
   if (!in) return az_fail(AZ_ERR_INVALID, "null search inputs");
+  if (d->variant == AZ_VARIANT_STOCHASTIC && !in->is_decision)
+    return az_fail(AZ_ERR_INVALID, "stochastic search needs the is_decision array");
   if (d->variant == AZ_VARIANT_GUMBEL) {
     if (!in->root_gumbel || !in->table)
       return az_fail(AZ_ERR_INVALID, "gumbel search needs root_gumbel and the considered-visits table");

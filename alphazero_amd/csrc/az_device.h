@@ -321,7 +321,7 @@ AZ_DEV void az_puct_scores(const SearchCtx& c, int A, const NodeRow<AMAX>& r, fl
   int32_t node_visit = r.node_visit;
   float pb_c = d.pb_c_init + az_logf((((float)node_visit + d.pb_c_base) + 1.0f) / d.pb_c_base);
   float probs[AMAX], value_score[AMAX];
-  if (d.variant == AZ_VARIANT_MUZERO) {
+  if (d.variant == AZ_VARIANT_MUZERO || d.variant == AZ_VARIANT_STOCHASTIC) {
     az_softmax<AMAX>(r.logits, A, probs);
   } else {
 AZ_UNROLL_A
@@ -469,7 +469,29 @@ AZ_DEV void az_simulate_lane(const SearchCtx& c, const Lane<AMAX, KMAX>& l, int 
     node = nxt;
     NodeRow<AMAX> r;
     az_load_row<AMAX, KMAX>(l, node, r);
-    if (d.variant != AZ_VARIANT_GUMBEL) {
+    if (d.variant == AZ_VARIANT_STOCHASTIC) {
+      // policies.py:676-708: the node's kind decides.  The key is split at every level
+      // (search.py:155) whether or not the selection draws from it.
+      const int AD = d.num_decision_actions;
+      float noise[AMAX];
+      az_puct_noise<AMAX>(c, AD, b, sim, depth, k0, k1, noise);
+      if (c.in.is_decision[(size_t)b * (d.S + 1) + node] != 0) {
+        // muzero_action_selection on the tree masked to its first AD columns (policies.py:658-673):
+        // a prefix of the row, so the rule runs on the row as loaded with AD in place of A
+        // (the caller's invalid_actions are [B, AD]: search() gets them unpadded, policies.py:472)
+        act = az_select_puct<AMAX>(c, AD, depth, r, noise, az_root_inputs(c, AD, b));
+      } else {
+        // policies.py:684-694: argmax(softmax(chance logits) / (visits + 1)) over the other columns
+        float x[AMAX], p[AMAX];
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a) x[a] = a < A - AD ? l.clog[node * A + AD + a] : 0.0f;
+        az_softmax<AMAX>(x, A - AD, p);
+AZ_UNROLL_A
+        for (int a = 0; a < AZ_TRIP_A; ++a)
+          if (a < A - AD) p[a] = p[a] / (float)(l.cvis[node * A + AD + a] + 1);
+        act = az_argmax<AMAX>(p, A - AD) + AD;
+      }
+    } else if (d.variant != AZ_VARIANT_GUMBEL) {
       float noise[AMAX];
       az_puct_noise<AMAX>(c, A, b, sim, depth, k0, k1, noise);
       act = az_select_puct<AMAX>(c, A, depth, r, noise, az_root_inputs(c, A, b));

@@ -608,6 +608,8 @@ extern "C" int az_search_fused(const az_search_desc* d, const az_tree* t,
   if (int rc = az_model_dev(m, &md)) return rc;
   if (!t->emb_state || !t->emb_time)
     return az_fail(AZ_ERR_INVALID, "fused search needs the tree's emb_state / emb_time arrays");
+  if (d->variant == AZ_VARIANT_STOCHASTIC)
+    return az_fail(AZ_ERR_UNSUPPORTED, "the stochastic variant runs on az_simulate / az_expand_backward only");
   if (d->A != md.A || d->K != md.K)
     return az_fail(AZ_ERR_INVALID, "search A=%d K=%d do not match the model's A=%d K=%d", d->A,
                    d->K, md.A, md.K);

@@ -391,6 +391,8 @@ extern "C" int az_search_injected(const az_search_desc* d, const az_tree* t,
   if (int rc = az_check_inputs(d, in)) return rc;
   if (!inj || !inj->prior_logits || !inj->value || !inj->reward || !inj->discount)
     return az_fail(AZ_ERR_INVALID, "null injected evaluation arrays");
+  if (d->variant == AZ_VARIANT_STOCHASTIC)
+    return az_fail(AZ_ERR_UNSUPPORTED, "the stochastic variant runs on az_simulate / az_expand_backward only");
   SearchCtx c{*d, *in};
   if (d->kernel_form == 0 && d->A == 2 && d->K == 1 && d->variant == AZ_VARIANT_GUMBEL && az_rule_of(d) == 1 &&
       d->S + 1 <= 65535 && az_aos_lds_bytes(d->S) <= 160 * 1024) {

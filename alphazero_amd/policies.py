@@ -127,6 +127,109 @@ def sampled_muzero_policy(params, rng_key, root, recurrent_fn, num_simulations, 
     return _visit_count_output(search_tree, rng_key, temperature, action_gumbel)
 
 
+def _make_stochastic_recurrent_fn(decision_node_fn, chance_node_fn, num_actions, num_chance_outcomes):
+    """mctx_dist/_src/policies.py:569-639: one recurrent_fn over A + C "actions".  Both node
+    functions are evaluated for every lane and the parent's kind picks the result; the halves
+    of the logits that belong to the other kind of node are -inf and never read."""
+
+    def stochastic_recurrent_fn(params, rng, action_or_chance, state):
+        B = action_or_chance.shape[0]
+        dev = action_or_chance.device
+        action = action_or_chance - 0
+        chance_outcome = action_or_chance - num_actions
+        decision_output, afterstate_embedding = decision_node_fn(params, rng, action, state.state_embedding)
+        av = decision_output.afterstate_value
+        neg_a = torch.full((B, num_actions), float("-inf"), dtype=torch.float32, device=dev)
+        neg_c = torch.full((B, num_chance_outcomes), float("-inf"), dtype=torch.float32, device=dev)
+        if_decision = base.RecurrentFnOutput(
+            prior_logits=torch.cat([neg_a, _f32(decision_output.chance_logits)], dim=-1),
+            value=av, reward=torch.zeros_like(av), discount=torch.ones_like(av))
+        chance_output, state_embedding = chance_node_fn(params, rng, chance_outcome,
+                                                        state.afterstate_embedding)
+        if_chance = base.RecurrentFnOutput(
+            prior_logits=torch.cat([_f32(chance_output.action_logits), neg_c], dim=-1),
+            value=chance_output.value, reward=chance_output.reward, discount=chance_output.discount)
+        new_state = base.StochasticRecurrentState(
+            state_embedding=state_embedding, afterstate_embedding=afterstate_embedding,
+            is_decision_node=torch.logical_not(state.is_decision_node))
+
+        def pick(decision_leaf, chance_leaf):
+            is_decision = state.is_decision_node.reshape([-1] + [1] * (decision_leaf.dim() - 1))
+            return torch.where(is_decision, decision_leaf, chance_leaf)
+        output = base.RecurrentFnOutput(
+            reward=pick(if_decision.reward, if_chance.reward),
+            discount=pick(if_decision.discount, if_chance.discount),
+            prior_logits=pick(if_decision.prior_logits, if_chance.prior_logits),
+            value=pick(if_decision.value, if_chance.value))
+        return output, new_state
+
+    return stochastic_recurrent_fn
+
+
+def _mask_tree(tree, num_actions, mode):
+    """mctx_dist/_src/policies.py:642-673: the columns of decision nodes ('decision') or of
+    chance nodes ('chance') of every [.., A + C] array, as contiguous copies."""
+    if mode == "decision":
+        take = lambda x: x[:, :, :num_actions].contiguous()
+        take_root = lambda x: x[:, :num_actions].contiguous()
+    elif mode == "chance":
+        take = lambda x: x[:, :, num_actions:].contiguous()
+        take_root = lambda x: x[:, num_actions:].contiguous()
+    else:
+        raise ValueError(f"Unknown mode: {mode}.")
+    return tree.replace(
+        children_index=take(tree.children_index),
+        children_prior_logits=take(tree.children_prior_logits),
+        children_visits=take(tree.children_visits),
+        children_rewards=take(tree.children_rewards),
+        children_discounts=take(tree.children_discounts),
+        children_values=take(tree.children_values),
+        root_invalid_actions=take_root(tree.root_invalid_actions))
+
+
+def stochastic_muzero_policy(params, rng_key, root, decision_recurrent_fn, chance_recurrent_fn,
+                             num_simulations, invalid_actions=None, max_depth=None, loop_fn=None, *,
+                             qtransform=qtransforms.qtransform_by_parent_and_siblings,
+                             dirichlet_fraction=0.25, dirichlet_alpha=0.3, pb_c_init=1.25,
+                             pb_c_base=19652, temperature=1.0, dirichlet_noise=None,
+                             tiebreak_noise=None, action_gumbel=None, stats=None):
+    """mctx_dist/_src/policies.py:346-483.  The two node functions are arbitrary callables, so
+    the search runs on the per-simulation kernels (az_simulate / az_expand_backward) around them."""
+    _check_floats(dirichlet_alpha=dirichlet_alpha, dirichlet_fraction=dirichlet_fraction)
+    lib = nat.lib()
+    rng_key, dirichlet_rng_key, search_rng_key = prng.split(rng_key, 3)
+    logits, noise, inv = _root_muzero_logits(root, invalid_actions, dirichlet_noise,
+                                             dirichlet_rng_key, dirichlet_fraction, dirichlet_alpha)
+    B, A = logits.shape
+    noisy_logits = torch.empty_like(logits)
+    nat.check(lib.az_root_muzero(B, A, nat.ptr(logits), nat.ptr(noise), float(dirichlet_fraction),
+                                 nat.ptr(inv), nat.ptr(noisy_logits), nat.stream_ptr()))
+    # a dummy afterstate embedding for the root (policies.py:419-424)
+    dummy_action = torch.zeros((B,), dtype=torch.int32, device=logits.device)
+    dummy_output, dummy_afterstate_embedding = decision_recurrent_fn(params, rng_key, dummy_action,
+                                                                     root.embedding)
+    C_ = dummy_output.chance_logits.shape[-1]
+    root = root.replace(
+        prior_logits=torch.cat([noisy_logits, torch.full((B, C_), float("-inf"), dtype=torch.float32,
+                                                         device=logits.device)], dim=-1),
+        embedding=base.StochasticRecurrentState(
+            state_embedding=root.embedding, afterstate_embedding=dummy_afterstate_embedding,
+            is_decision_node=torch.ones((B,), dtype=torch.bool, device=logits.device)))
+    recurrent_fn = _make_stochastic_recurrent_fn(decision_recurrent_fn, chance_recurrent_fn, A, C_)
+    decision_fn = functools.partial(action_selection.muzero_action_selection, pb_c_base=pb_c_base,
+                                    pb_c_init=pb_c_init, qtransform=qtransform)
+    interior = functools.partial(action_selection.stochastic_muzero_action_selection,
+                                 decision_node_selection_fn=decision_fn, num_actions=A)
+    root_fn = functools.partial(interior, depth=0)
+    search_tree = search_lib.search(
+        params=params, rng_key=search_rng_key, root=root, recurrent_fn=recurrent_fn,
+        root_action_selection_fn=root_fn, interior_action_selection_fn=interior,
+        num_simulations=num_simulations, max_depth=max_depth, invalid_actions=invalid_actions,
+        loop_fn=loop_fn, tiebreak_noise=tiebreak_noise, stats=stats)
+    search_tree = _mask_tree(search_tree, A, "decision")
+    return _visit_count_output(search_tree, rng_key, temperature, action_gumbel)
+
+
 def _visit_count_output(search_tree, rng_key, temperature, action_gumbel):
     """policies.py:113-122 / 225-234: weights = root visit probabilities, action =
     categorical(log weights / temperature)."""

@@ -98,8 +98,10 @@ def build_desc(*, B, S, A, K, root_action_selection_fn, interior_action_selectio
     elif isinstance(tiebreak_noise, str) and tiebreak_noise == "zero":
         d.noise_mode, d.noise_depth = nat.NOISE_ZERO, 0
     else:
+        # (the noise of a stochastic search is drawn for the decision nodes' actions only)
+        An = d.num_decision_actions if d.variant == nat.VARIANT_STOCHASTIC else A
         if tiebreak_noise.dim() != 4 or tiebreak_noise.shape[0] != B or \
-                tiebreak_noise.shape[1] != S or tiebreak_noise.shape[3] != A:
+                tiebreak_noise.shape[1] != S or tiebreak_noise.shape[3] != An:
             raise ValueError("tiebreak_noise must have shape [B, num_simulations, depth, A]")
         d.noise_mode, d.noise_depth = nat.NOISE_INJECTED, tiebreak_noise.shape[2]
     return d
@@ -148,8 +150,11 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
     if stats is not None and stats.get("kernel_form") == "literal":
         d.kernel_form = 1  # cross-checks: the one-thread-per-lane kernels
     inv = None if invalid_actions is None else _f32(invalid_actions, "invalid_actions")
-    if inv is not None and inv.shape != (B, A):
+    stochastic = d.variant == nat.VARIANT_STOCHASTIC
+    if inv is not None and inv.shape != (B, d.num_decision_actions if stochastic else A):
         raise ValueError("invalid_actions must have shape [B, num_actions]")
+    if stochastic and isinstance(recurrent_fn, (FusedRecurrentFn, InjectedRecurrentFn)):
+        raise NotImplementedError("the stochastic search runs around caller-side node functions")
 
     inputs = nat.SearchInputs()
     keep = [logits, value2, inv, noise]
@@ -220,6 +225,12 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
             buf[:, 0] = x
             return buf
         embeddings = tree_map(_alloc, root.embedding)
+        if stochastic:
+            # the kind of every node, [B, N] bytes, which the selection kernel reads in place
+            kind = embeddings.is_decision_node
+            if kind.dtype != torch.bool or kind.shape != (B, N):
+                raise ValueError("StochasticRecurrentState.is_decision_node must be a [B] bool tensor")
+            inputs.is_decision = nat.ptr(kind)
         parent = torch.empty((B,), dtype=torch.int32, device=dev)
         action = torch.empty((B,), dtype=torch.int32, device=dev)
         nxt = torch.empty((B,), dtype=torch.int32, device=dev)

@@ -27,7 +27,7 @@ extern "C" {
 #define AZ_MAX_WIDTH 1024 /* widest dense layer the fused networks accept */
 
 enum { AZ_OK = 0, AZ_ERR_INVALID = -1, AZ_ERR_UNSUPPORTED = -2, AZ_ERR_HIP = -3 };
-enum { AZ_VARIANT_MUZERO = 0, AZ_VARIANT_SAMPLED = 1, AZ_VARIANT_GUMBEL = 2 };
+enum { AZ_VARIANT_MUZERO = 0, AZ_VARIANT_SAMPLED = 1, AZ_VARIANT_GUMBEL = 2, AZ_VARIANT_STOCHASTIC = 3 };
 enum { AZ_QT_PARENT_SIBLINGS = 0, AZ_QT_COMPLETED_MIX = 1, AZ_QT_MIN_MAX = 2 };
 enum { AZ_ENV_CARTPOLE = 1, AZ_ENV_MOUNTAINCAR = 2, AZ_ENV_ACROBOT = 3 };
 enum { AZ_NOISE_THREEFRY = 0, AZ_NOISE_INJECTED = 1, AZ_NOISE_ZERO = 2 };
@@ -50,6 +50,9 @@ typedef struct az_search_desc {
   int32_t noise_depth;         /* Dn of an injected noise tensor [B,S,Dn,A]         */
   uint32_t key[2];             /* rng_key handed to search()                        */
   int32_t kernel_form;         /* 0: automatic; 1: the one-thread-per-lane kernels  */
+  int32_t num_decision_actions; /* AZ_VARIANT_STOCHASTIC (policies.py:346-483): of the A columns the
+                                * first num_decision_actions are the actions of decision nodes and the
+                                * rest the chance outcomes of chance nodes (policies.py:584-589)       */
 } az_search_desc;
 
 /* The search tree, in exactly the reference's array layout
@@ -75,10 +78,15 @@ typedef struct az_tree {
 
 /* Per-search inputs shared by the search entry points. */
 typedef struct az_search_inputs {
-  const float* invalid_actions; /* [B,A] 1 = invalid, or NULL (search.py:85-86)            */
+  const float* invalid_actions; /* [B,A] 1 = invalid, or NULL (search.py:85-86); [B,num_decision_actions]
+                                 * for AZ_VARIANT_STOCHASTIC                                */
   const float* root_gumbel;     /* [B,A] GumbelMuZeroExtraData.root_gumbel, gumbel variant */
   const int32_t* table;         /* [(m+1),S] from az_considered_table, gumbel variant      */
-  const float* noise;           /* [B,S,Dn,A] uniform draws when noise_mode = INJECTED     */
+  const float* noise;           /* [B,S,Dn,A] uniform draws when noise_mode = INJECTED
+                                 * ([B,S,Dn,num_decision_actions] for AZ_VARIANT_STOCHASTIC) */
+  const uint8_t* is_decision;   /* [B,N] 1 = decision node, 0 = chance node (the is_decision_node leaf of
+                                 * StochasticRecurrentState, base.py:141-161, kept by the caller next to
+                                 * its embeddings); AZ_VARIANT_STOCHASTIC only                          */
   const uint32_t* sim_keys;     /* [S,2] the output of az_sim_keys copied to the device, or NULL: the
                                  * cooperative kernels then derive the keys themselves, one thread
                                  * of every workgroup walking the sequential chain (read with
@@ -152,6 +160,9 @@ int az_search_injected(const az_search_desc* d, const az_tree* t, const az_searc
 
 /* mctx_dist/_src/search.py:93-99: simulate for simulation `sim`; writes the parent
  * node, the action to expand and the index of the node to (re)evaluate, each [B]. */
+/* AZ_VARIANT_STOCHASTIC (policies.py:676-708) runs on this entry point only: decision nodes
+ * select with the muzero rule over their first num_decision_actions columns, chance nodes take
+ * argmax(softmax(chance logits) / (visits + 1)) over the rest. */
 int az_simulate(const az_search_desc* d, const az_tree* t, const az_search_inputs* in,
                 int32_t sim, int32_t* parent, int32_t* action, int32_t* next,
                 int64_t* sum_depth, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MAX_LAYERS = 8
-VARIANTS = {"muzero": 0, "sampled": 1, "gumbel": 2}
+VARIANTS = {"muzero": 0, "sampled": 1, "gumbel": 2, "stochastic": 3}
 QTRANSFORMS = {"parent_and_siblings": 0, "completed_by_mix_value": 1, "min_max": 2}
 ENVS = {"none": 0, "CartPole-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3}
 NOISE = {"threefry": 0, "injected": 1, "zero": 2}
@@ -43,7 +43,7 @@ class Cfg(C.Structure):
         ("rescale_values", C.c_int32), ("use_mixed_value", C.c_int32),
         ("min_value", C.c_float), ("max_value", C.c_float),
         ("max_num_considered", C.c_int32), ("noise_mode", C.c_int32),
-        ("noise_depth", C.c_int32), ("key", C.c_uint32 * 2),
+        ("noise_depth", C.c_int32), ("key", C.c_uint32 * 2), ("num_decision_actions", C.c_int32),
     ]
 
 
@@ -84,7 +84,7 @@ def make_cfg(B, S, A, K=1, variant="gumbel", max_depth=None, qtransform=None,
              pb_c_init=1.25, pb_c_base=19652.0, q_epsilon=1e-8, value_scale=0.1,
              maxvisit_init=50.0, rescale_values=True, use_mixed_value=True,
              min_value=0.0, max_value=1.0, max_num_considered=16, noise_mode="zero",
-             noise_depth=0, key=(0, 0)):
+             noise_depth=0, key=(0, 0), num_decision_actions=0):
     if qtransform is None:
         qtransform = "completed_by_mix_value" if variant == "gumbel" else "parent_and_siblings"
     c = Cfg()
@@ -100,6 +100,7 @@ def make_cfg(B, S, A, K=1, variant="gumbel", max_depth=None, qtransform=None,
     c.noise_mode = NOISE[noise_mode]
     c.noise_depth = noise_depth
     c.key[0], c.key[1] = int(key[0]), int(key[1])
+    c.num_decision_actions = num_decision_actions
     return c
 
 
@@ -183,6 +184,27 @@ def search_injected(cfg, tree, evals, invalid=None, root_gumbel=None, noise=None
     lib().oz_search_injected(C.byref(cfg), C.byref(ts), _p(inv), _p(g), _p(nz), C.byref(inj),
                              C.byref(sd))
     return sd.value
+
+
+class InjectedStochastic(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("chance_logits", "afterstate_value", "action_logits", "value",
+                                           "reward", "discount")]
+
+
+def search_stochastic(cfg, tree, evals, invalid=None, noise=None):
+    """evals: dict(chance_logits[B,S,C], afterstate_value[B,S,K], action_logits[B,S,AD], value[B,S,K],
+    reward[B,S], discount[B,S]).  Returns (is_decision [B,N] uint8, sum of depths)."""
+    inj = InjectedStochastic()
+    keep = {k: _f32(v) for k, v in evals.items()}
+    for k, _ in InjectedStochastic._fields_:
+        setattr(inj, k, _p(keep[k]))
+    inv, nz = _f32(invalid), _f32(noise)
+    ts = _tree_struct(tree)
+    kind = np.zeros((cfg.B, cfg.S + 1), np.uint8)
+    sd = C.c_int64(0)
+    lib().oz_search_stochastic(C.byref(cfg), C.byref(ts), _p(inv), _p(nz), C.byref(inj), _p(kind),
+                               C.byref(sd))
+    return kind, sd.value
 
 
 def search_model(cfg, tree, model, invalid=None, root_gumbel=None, noise=None):

@@ -17,6 +17,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include "../alphazero_amd/csrc/az_math.h"
 
@@ -252,6 +253,7 @@ typedef struct {
   const float* root_gumbel;  /* [B,A] (gumbel variant) */
   const int32_t* table;      /* [(m+1),S] */
   const float* noise;        /* injected tie-break noise [B,S,Dn,A] or NULL */
+  const uint8_t* is_decision; /* [B,N] node kinds (stochastic variant) */
 } search_t;
 
 /* mctx_dist/_src/action_selection.py:48-90 (muzero) and :93-135 (sampled). */
@@ -263,7 +265,7 @@ static int oz_select_puct(const search_t* s, const lane_t* l, int b, int node, i
   int32_t node_visit = l->node_visits[node];
   float pb_c = c->pb_c_init + az_logf((((float)node_visit + c->pb_c_base) + 1.0f) / c->pb_c_base);
   float probs[OZ_MAX_A], value_score[OZ_MAX_A], to_argmax[OZ_MAX_A];
-  if (c->variant == OZ_VARIANT_MUZERO)
+  if (c->variant == OZ_VARIANT_MUZERO || c->variant == OZ_VARIANT_STOCHASTIC)
     oz_softmax(l->clogits + node * A, A, probs);
   else
     for (int a = 0; a < A; ++a) probs[a] = l->clogits[node * A + a];
@@ -316,6 +318,48 @@ static int oz_select_gumbel_interior(const search_t* s, const lane_t* l, int nod
   return oz_argmax(to_argmax, A);
 }
 
+/* mctx_dist/_src/policies.py:676-708: the node's kind picks the rule.  Decision nodes run
+ * muzero_action_selection on the tree masked to its first AD columns (policies.py:658-673),
+ * restated here by copying the node's AD columns into a one-node lane of width AD; chance
+ * nodes take argmax(softmax(chance logits) / (visits + 1)) over the other columns. */
+static int oz_select_stochastic(const search_t* s, const lane_t* l, int b, int node, int depth,
+                                const float* noise) {
+  const oz_cfg* c = s->c;
+  int A = l->A, K = l->K, AD = c->num_decision_actions, CN = A - AD;
+  if (s->is_decision[(size_t)b * l->N + node]) {
+    int32_t vis[OZ_MAX_A], idx[OZ_MAX_A];
+    float lg[OZ_MAX_A], rw[OZ_MAX_A], dc[OZ_MAX_A], cv[OZ_MAX_A * OZ_MAX_K], inv[OZ_MAX_A];
+    for (int a = 0; a < AD; ++a) {
+      vis[a] = l->cvisits[node * A + a];
+      idx[a] = l->cindex[node * A + a];
+      lg[a] = l->clogits[node * A + a];
+      rw[a] = l->crew[node * A + a];
+      dc[a] = l->cdisc[node * A + a];
+      for (int k = 0; k < K; ++k) cv[a * K + k] = l->cval[((size_t)node * A + a) * K + k];
+      inv[a] = s->invalid[(size_t)b * AD + a]; /* search() gets [B,AD] (policies.py:472) */
+    }
+    lane_t m = *l;
+    m.N = 1;
+    m.A = AD;
+    m.node_visits = l->node_visits + node;
+    m.raw = l->raw + (size_t)node * K;
+    m.nval = l->nval + (size_t)node * K;
+    m.cvisits = vis;
+    m.cindex = idx;
+    m.clogits = lg;
+    m.crew = rw;
+    m.cdisc = dc;
+    m.cval = cv;
+    search_t s2 = *s;
+    s2.invalid = inv;
+    return oz_select_puct(&s2, &m, 0, 0, depth, noise);
+  }
+  float p[OZ_MAX_A];
+  oz_softmax(l->clogits + node * A + AD, CN, p);
+  for (int a = 0; a < CN; ++a) p[a] = p[a] / (float)(l->cvisits[node * A + AD + a] + 1);
+  return oz_argmax(p, CN) + AD;
+}
+
 /* mctx_dist/_src/search.py:127-187 with the root/interior switch of
  * action_selection.py:28-45.  `lane_key` is split(simulate_key, B)[b]. */
 static void oz_simulate(const search_t* s, const lane_t* l, int b, int sim,
@@ -335,19 +379,22 @@ static void oz_simulate(const search_t* s, const lane_t* l, int b, int sim,
       az_key_split(k0, k1, 1u, &s0, &s1);
       k0 = n0;
       k1 = n1;
-      for (int a = 0; a < A; ++a) {
+      /* (stochastic: uniform(key, [AD]) -- the masked tree's width, policies.py:703-704) */
+      const int An = c->variant == OZ_VARIANT_STOCHASTIC ? c->num_decision_actions : A;
+      for (int a = 0; a < An; ++a) {
         float u;
         if (c->noise_mode == OZ_NOISE_THREEFRY)
           u = az_uniform_from_bits(az_random_bits32(s0, s1, (uint32_t)a), 0.0f, 1.0f);
         else if (c->noise_mode == OZ_NOISE_INJECTED)
           u = depth < c->noise_depth
-                  ? s->noise[(((size_t)b * c->S + sim) * c->noise_depth + depth) * A + a]
+                  ? s->noise[(((size_t)b * c->S + sim) * c->noise_depth + depth) * An + a]
                   : 0.0f;
         else
           u = 0.0f;
         noise[a] = 1e-7f * u; /* action_selection.py:85-86 */
       }
-      action = oz_select_puct(s, l, b, node, depth, noise);
+      action = c->variant == OZ_VARIANT_STOCHASTIC ? oz_select_stochastic(s, l, b, node, depth, noise)
+                                                    : oz_select_puct(s, l, b, node, depth, noise);
     } else if (depth == 0) {
       action = oz_select_gumbel_root(s, l, b, node);
     } else {
@@ -720,7 +767,7 @@ static void oz_search_impl(const oz_cfg* c, const oz_tree* t, const float* inval
     zero_invalid = (float*)calloc((size_t)B * A, sizeof(float));
     invalid = zero_invalid;
   }
-  search_t s = {c, invalid, root_gumbel, table, noise};
+  search_t s = {c, invalid, root_gumbel, table, noise, NULL};
   /* per-simulation keys: rng, simulate_key, expand_key = split(rng, 3) */
   uint32_t* sim_keys = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)S);
   {
@@ -770,6 +817,70 @@ static void oz_search_impl(const oz_cfg* c, const oz_tree* t, const float* inval
   if (sum_depth) *sum_depth = total_depth;
   free(sim_keys);
   free(table);
+  free(zero_invalid);
+}
+
+/* mctx_dist/_src/policies.py:346-483, 569-639: the search of stochastic_muzero_policy with the
+ * outputs of both node functions injected per (lane, simulation).  `t` has A = AD + C columns
+ * and was initialised with the root's logits padded with -inf (policies.py:426-431);
+ * `is_decision` [B,N] receives the kind of every node (the root is a decision node, a child is
+ * of the other kind than its parent, policies.py:620-623). */
+void oz_search_stochastic(const oz_cfg* c, const oz_tree* t, const float* invalid, const float* noise,
+                          const oz_injected_stochastic* inj, uint8_t* is_decision, int64_t* sum_depth) {
+  int B = c->B, S = c->S, A = c->A, K = c->K, AD = c->num_decision_actions, CN = A - AD, N = S + 1;
+  float* zero_invalid = NULL;
+  if (!invalid) {
+    zero_invalid = (float*)calloc((size_t)B * A, sizeof(float));
+    invalid = zero_invalid;
+  }
+  search_t s = {c, invalid, NULL, NULL, noise, is_decision};
+  uint32_t* sim_keys = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)S);
+  {
+    uint32_t r0 = c->key[0], r1 = c->key[1];
+    for (int sim = 0; sim < S; ++sim) {
+      uint32_t n0, n1;
+      az_key_split(r0, r1, 1u, &sim_keys[2 * sim], &sim_keys[2 * sim + 1]);
+      az_key_split(r0, r1, 0u, &n0, &n1);
+      r0 = n0;
+      r1 = n1;
+    }
+  }
+  int64_t total_depth = 0;
+  for (int b = 0; b < B; ++b) {
+    lane_t l = oz_lane(t, c, b);
+    uint8_t* kind = is_decision + (size_t)b * N;
+    for (int n = 0; n < N; ++n) kind[n] = 0;
+    kind[ROOT_INDEX] = 1;
+    for (int sim = 0; sim < S; ++sim) {
+      uint32_t lk0, lk1;
+      az_key_split(sim_keys[2 * sim], sim_keys[2 * sim + 1], (uint32_t)b, &lk0, &lk1);
+      int parent, action, nxt, depth;
+      oz_simulate(&s, &l, b, sim, lk0, lk1, &parent, &action, &nxt, &depth);
+      int node = (nxt == UNVISITED) ? sim + 1 : nxt;
+      total_depth += depth;
+      float logits[OZ_MAX_A], value[OZ_MAX_K], reward, discount;
+      size_t e = (size_t)b * S + sim;
+      if (kind[parent]) { /* policies.py:597-603 */
+        for (int a = 0; a < AD; ++a) logits[a] = -INFINITY;
+        for (int a = 0; a < CN; ++a) logits[AD + a] = inj->chance_logits[e * CN + a];
+        for (int k = 0; k < K; ++k) value[k] = inj->afterstate_value[e * K + k];
+        reward = 0.0f;
+        discount = 1.0f;
+      } else { /* policies.py:611-618 */
+        for (int a = 0; a < AD; ++a) logits[a] = inj->action_logits[e * AD + a];
+        for (int a = 0; a < CN; ++a) logits[AD + a] = -INFINITY;
+        for (int k = 0; k < K; ++k) value[k] = inj->value[e * K + k];
+        reward = inj->reward[e];
+        discount = inj->discount[e];
+      }
+      uint8_t new_kind = !kind[parent];
+      oz_expand_write(&l, parent, action, node, logits, value, reward, discount);
+      kind[node] = new_kind;
+      oz_backward(&l, node);
+    }
+  }
+  if (sum_depth) *sum_depth = total_depth;
+  free(sim_keys);
   free(zero_invalid);
 }
 

@@ -21,7 +21,7 @@
 #define OZ_MAX_A 64
 #define OZ_MAX_K 64
 
-enum { OZ_VARIANT_MUZERO = 0, OZ_VARIANT_SAMPLED = 1, OZ_VARIANT_GUMBEL = 2 };
+enum { OZ_VARIANT_MUZERO = 0, OZ_VARIANT_SAMPLED = 1, OZ_VARIANT_GUMBEL = 2, OZ_VARIANT_STOCHASTIC = 3 };
 enum { OZ_QT_PARENT_SIBLINGS = 0, OZ_QT_COMPLETED_MIX = 1, OZ_QT_MIN_MAX = 2 };
 enum { OZ_ENV_NONE = 0, OZ_ENV_CARTPOLE = 1, OZ_ENV_MOUNTAINCAR = 2, OZ_ENV_ACROBOT = 3 };
 enum { OZ_NOISE_THREEFRY = 0, OZ_NOISE_INJECTED = 1, OZ_NOISE_ZERO = 2 };
@@ -40,6 +40,8 @@ typedef struct {
   int32_t noise_mode;  /* PUCT tie-break noise source */
   int32_t noise_depth; /* Dn of an injected noise tensor [B,S,Dn,A] */
   uint32_t key[2];     /* the rng_key handed to search() */
+  int32_t num_decision_actions; /* OZ_VARIANT_STOCHASTIC: of the A = AD + C columns the first AD are
+                                 * actions, the rest chance outcomes (policies.py:584-589) */
 } oz_cfg;
 
 /* Tree arrays in the reference's layout (mctx_dist/_src/tree.py:60-73). */
@@ -82,5 +84,16 @@ typedef struct {
   const float* reward;       /* [B,S]   */
   const float* discount;     /* [B,S]   */
 } oz_injected;
+
+/* Stochastic MuZero: what the two node functions return per (lane, simulation)
+ * (mctx_dist/_src/base.py:103-139); the parent's kind picks one of them. */
+typedef struct {
+  const float* chance_logits;    /* [B,S,C] DecisionRecurrentFnOutput */
+  const float* afterstate_value; /* [B,S,K] */
+  const float* action_logits;    /* [B,S,AD] ChanceRecurrentFnOutput */
+  const float* value;            /* [B,S,K]  */
+  const float* reward;           /* [B,S]    */
+  const float* discount;         /* [B,S]    */
+} oz_injected_stochastic;
 
 #endif

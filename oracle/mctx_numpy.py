@@ -194,6 +194,53 @@ def gumbel_interior_action_selection(tree, node, *, qtransform):
     return int(np.argmax(to_argmax))
 
 
+class MaskedLaneTree:
+    """mctx_dist/_src/policies.py:642-673 (_mask_tree) on one lane: columns [lo, hi) of every
+    per-action array, everything else shared."""
+
+    def __init__(self, t, lo, hi):
+        self.node_visits, self.raw_values, self.node_values = t.node_visits, t.raw_values, t.node_values
+        self.children_index = t.children_index[:, lo:hi]
+        self.children_prior_logits = t.children_prior_logits[:, lo:hi]
+        self.children_visits = t.children_visits[:, lo:hi]
+        self.children_rewards = t.children_rewards[:, lo:hi]
+        self.children_discounts = t.children_discounts[:, lo:hi]
+        self.children_values = t.children_values[:, lo:hi]
+
+    qvalues = LaneTree.qvalues
+
+
+def stochastic_action_selection(noise, tree, node, depth, *, invalid, num_actions, **puct_kwargs):
+    """mctx_dist/_src/policies.py:676-708.  The node's embedding is (state, afterstate,
+    is_decision_node); ``noise`` is the uniform(key, (num_actions,)) draw of the decision rule."""
+    if tree.embeddings[node][2]:
+        return puct_action_selection(noise, MaskedLaneTree(tree, 0, num_actions), node, depth,
+                                     invalid=invalid, sampled=False, **puct_kwargs)
+    chance = MaskedLaneTree(tree, num_actions, tree.A)
+    prob_chance = softmax(chance.children_prior_logits[node])
+    return int(np.argmax((prob_chance / (chance.children_visits[node] + 1).astype(f32)).astype(f32))) + num_actions
+
+
+def make_stochastic_recurrent_fn(decision_fn, chance_fn, num_actions, num_chance_outcomes):
+    """mctx_dist/_src/policies.py:569-639 for one lane: ``decision_fn(sim, action, state)`` returns
+    (chance_logits[C], afterstate_value[K], afterstate), ``chance_fn(sim, outcome, afterstate)``
+    (action_logits[A], value[K], reward, discount, state); both are evaluated and the parent's
+    kind picks."""
+    def recurrent_fn(sim, action_or_chance, emb):
+        state, afterstate, is_decision = emb
+        chance_logits, afterstate_value, new_afterstate = decision_fn(sim, action_or_chance, state)
+        action_logits, value, reward, discount, new_state = chance_fn(
+            sim, action_or_chance - num_actions, afterstate)
+        neg_a = np.full(num_actions, -np.inf, f32)
+        neg_c = np.full(num_chance_outcomes, -np.inf, f32)
+        new_emb = (new_state, new_afterstate, not is_decision)
+        if is_decision:
+            return (f32(0), f32(1), np.concatenate([neg_a, chance_logits]).astype(f32),
+                    afterstate_value, new_emb)
+        return reward, discount, np.concatenate([action_logits, neg_c]).astype(f32), value, new_emb
+    return recurrent_fn
+
+
 # ---------------------------------------------------------------- search
 def search_lane(*, root_logits, root_value, root_embedding, recurrent_fn, num_simulations,
                 select, max_depth=None):

@@ -179,6 +179,113 @@ def run_policy_numpy(case):
     return out
 
 
+# ---------------------------------------------------------------- stochastic MuZero
+def synthetic_stochastic_case(B, S, A, C, seed=0, *, max_depth=None, with_invalid=False):
+    """Random inputs for one stochastic_muzero_policy call: what the decision and the chance
+    node function return per (lane, simulation), scalar values (mctx_dist/_src/base.py:103-139)."""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    case = dict(variant="stochastic", B=B, S=S, A=A, C=C, K=1, max_depth=max_depth, invalid=None,
+                temperature=1.0)
+    if with_invalid:
+        inv = (rng.uniform(size=(B, A)) < 0.3).astype(f)
+        inv[0, :] = 1.0
+        if B > 1:
+            inv[1, :] = 0.0
+        case["invalid"] = inv
+    case["prior_logits"] = rng.normal(size=(B, A)).astype(f)
+    case["value"] = rng.uniform(-1, 1, size=(B, 1)).astype(f)
+    case["evals"] = dict(
+        chance_logits=rng.normal(size=(B, S, C)).astype(f),
+        afterstate_value=rng.uniform(-1, 1, size=(B, S, 1)).astype(f),
+        action_logits=rng.normal(size=(B, S, A)).astype(f),
+        value=rng.uniform(-1, 1, size=(B, S, 1)).astype(f),
+        reward=rng.uniform(0, 1, size=(B, S)).astype(f),
+        discount=np.full((B, S), 0.99, f))
+    case["dirichlet"] = rng.dirichlet([0.3] * A, size=B).astype(f)
+    u = rng.uniform(1e-6, 1.0, size=(B, A))
+    case["action_gumbel"] = (-np.log(-np.log(u))).astype(f)
+    case["tie_noise"] = rng.uniform(size=(B, S, max_depth or S, A)).astype(f)
+    return case
+
+
+def _mask_decision(tree, A):
+    """policies.py:476: the decision columns of every per-action array."""
+    out = {}
+    for k, v in tree.items():
+        out[k] = np.ascontiguousarray(v[:, :, :A]) if k.startswith("children_") else v
+    return out
+
+
+def run_stochastic_c(case):
+    """mctx_dist/_src/policies.py:346-483 on the C checker."""
+    B, S, A, C_ = case["B"], case["S"], case["A"], case["C"]
+    noise_mode = "injected" if case.get("tie_noise") is not None else "zero"
+    if case.get("search_key") is not None:  # the device generator keyed as search() keys it
+        noise_mode = "threefry"
+    cfg = co.make_cfg(B, S, A + C_, 1, variant="stochastic", max_depth=case.get("max_depth"),
+                      noise_mode=noise_mode, key=case.get("search_key") or (0, 0),
+                      noise_depth=0 if case.get("tie_noise") is None else case["tie_noise"].shape[2],
+                      num_decision_actions=A)
+    inv = case.get("invalid")
+    prior = co.root_muzero(case["prior_logits"], case["dirichlet"], 0.25, inv)
+    padded = np.concatenate([prior, np.full((B, C_), -np.inf, np.float32)], axis=-1)
+    tree = co.alloc_tree(B, S, A + C_, 1)
+    co.tree_init(cfg, tree, padded, case["value"])
+    kind, sum_depth = co.search_stochastic(cfg, tree, case["evals"], invalid=inv, noise=case.get("tie_noise"))
+    masked = _mask_decision(tree, A)
+    mcfg = co.make_cfg(B, S, A, 1, variant="muzero")
+    action, weights = co.epilogue_visits(mcfg, masked, case.get("temperature", 1.0),
+                                         gumbel=case["action_gumbel"])
+    out = dict(masked)
+    out.update(action=action, action_weights=weights, sum_depth=sum_depth, root_prior=prior,
+               is_decision=kind, full_tree=tree)
+    return out
+
+
+def run_stochastic_numpy(case):
+    """The same call on the NumPy checker."""
+    B, S, A, C_ = case["B"], case["S"], case["A"], case["C"]
+    ev = case["evals"]
+    lanes, actions, weights, priors, kinds = [], [], [], [], []
+    total_depth = 0
+    for b in range(B):
+        inv_in = None if case.get("invalid") is None else case["invalid"][b]
+        inv = np.zeros(A, np.float32) if inv_in is None else inv_in
+        prior = mn.root_logits_muzero(case["prior_logits"][b], case["dirichlet"][b], 0.25, inv_in)
+        padded = np.concatenate([prior, np.full(C_, -np.inf, np.float32)])
+
+        def select(tree, node, depth, sim, b=b, inv=inv):
+            tie = case.get("tie_noise")
+            noise = (tie[b, sim, depth] if tie is not None and depth < tie.shape[2]
+                     else np.zeros(A, np.float32))
+            return mn.stochastic_action_selection(noise, tree, node, depth, invalid=inv, num_actions=A)
+
+        def decision_fn(sim, action, state, b=b):
+            return ev["chance_logits"][b, sim], ev["afterstate_value"][b, sim], state + 1
+
+        def chance_fn(sim, outcome, afterstate, b=b):
+            return (ev["action_logits"][b, sim], ev["value"][b, sim], ev["reward"][b, sim],
+                    ev["discount"][b, sim], afterstate + 10)
+        rf = mn.make_stochastic_recurrent_fn(decision_fn, chance_fn, A, C_)
+        tree, sd = mn.search_lane(root_logits=padded, root_value=case["value"][b],
+                                  root_embedding=(0, 1, True), recurrent_fn=rf, num_simulations=S,
+                                  select=select, max_depth=case.get("max_depth"))
+        total_depth += sd
+        kinds.append(np.array([e[2] if e is not None else False for e in tree.embeddings], np.uint8))
+        a, w = mn.visit_epilogue(mn.MaskedLaneTree(tree, 0, A), case.get("temperature", 1.0),
+                                 case["action_gumbel"][b])
+        lanes.append(tree)
+        actions.append(a)
+        weights.append(w)
+        priors.append(prior)
+    out = {f: np.stack([getattr(t, f) for t in lanes]) for f in TREE_FIELDS}
+    out = _mask_decision(out, A)
+    out.update(action=np.array(actions, np.int32), action_weights=np.stack(weights),
+               sum_depth=total_depth, root_prior=np.stack(priors), is_decision=np.stack(kinds))
+    return out
+
+
 # ---------------------------------------------------------------- synthetic cases
 def lecun_uniform_mlp(rng, sizes):
     """flax lecun_uniform kernels U(+-sqrt(3/fan_in)), zero biases (networks.py:29)."""

