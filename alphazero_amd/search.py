@@ -12,7 +12,6 @@ drives one of three device paths, all writing the same Tree arrays:
 """
 import ctypes as C
 import dataclasses
-import numpy as np
 
 import torch
 
@@ -81,6 +80,35 @@ def _timed(stats, launch):
         stats.setdefault("events", []).append((start, end))
     else:
         launch()
+
+
+class _KeyRing:
+    """Pinned host slots for the per-simulation keys of consecutive searches: the keys go to the
+    device with an asynchronous copy (a copy from pageable memory would make the host wait for
+    everything queued on the stream, once per search), and a slot is written again only after the
+    copy that last read it has finished."""
+    SLOTS = 16
+
+    def __init__(self, S):
+        self.host = torch.empty((self.SLOTS, S, 2), dtype=torch.int32).pin_memory()
+        self.done = [None] * self.SLOTS
+        self.next = 0
+
+    def upload(self, lib, key, S, dev):
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        slot = self.host[i]
+        nat.check(lib.az_sim_keys(_key_words(key), S, C.c_void_p(slot.data_ptr())))
+        out = torch.empty((S, 2), dtype=torch.int32, device=dev)
+        out.copy_(slot, non_blocking=True)
+        self.done[i] = torch.cuda.Event()
+        self.done[i].record()
+        return out
+
+
+_key_rings = {}
 
 
 def build_desc(*, B, S, A, K, root_action_selection_fn, interior_action_selection_fn,
@@ -172,9 +200,10 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
     if d.noise_mode == nat.NOISE_THREEFRY and not (stats is not None and stats.get("sim_keys") == "device"):
         # the per-simulation keys (search.py:90) form a sequential chain: one CPU core walks it in
         # microseconds, one GPU thread per workgroup would take tens of them
-        host_keys = np.empty((S, 2), dtype=np.uint32)
-        nat.check(lib.az_sim_keys(_key_words((int(d.key[0]), int(d.key[1]))), S, host_keys.ctypes.data_as(C.c_void_p)))
-        sim_keys = torch.from_numpy(host_keys.view(np.int32)).to(dev)
+        ring = _key_rings.get((dev, S))
+        if ring is None:
+            ring = _key_rings[(dev, S)] = _KeyRing(S)
+        sim_keys = ring.upload(lib, (int(d.key[0]), int(d.key[1])), S, dev)
         inputs.sim_keys = nat.ptr(sim_keys)
         keep.append(sim_keys)
 
