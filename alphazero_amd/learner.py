@@ -136,8 +136,12 @@ def unpack_rows(layout, rows):
 
 
 def compute_muzero_loss(policy_layers, value_layers, mean, std, data, num_atoms, qr_kappa=1.0,
-                        vf_cost=0.5, l2_coef=1e-4, per_importance_sampling=True):
-    """alphazero.py:723-807 on a dict of batch fields; returns (total_loss, metrics)."""
+                        vf_cost=0.5, l2_coef=1e-4, per_importance_sampling=True, l2_outside_graph=False):
+    """alphazero.py:723-807 on a dict of batch fields; returns (total_loss, metrics).
+    l2_outside_graph: the L2 penalty enters the reported losses only, computed without autograd
+    in three launches; the caller adds its gradient, l2_coef * parameter, itself
+    (minibatch_step) -- the differentiable form costs about a hundred launches of a few
+    microseconds per minibatch for the 22 parameter leaves."""
     logits, baseline = forward_networks(policy_layers, value_layers, mean, std, data["observation"])
     lsm = F.log_softmax(logits, -1)
     policy_loss = -(data["target_policy_probs"].detach() * lsm).sum(-1).mean()
@@ -150,7 +154,12 @@ def compute_muzero_loss(policy_layers, value_layers, mean, std, data, num_atoms,
     if per_importance_sampling:
         v_losses = v_losses * data["weight"]
     v_loss = vf_cost * v_losses.mean()
-    l2 = l2_coef * 0.5 * sum((w ** 2).sum() + (b ** 2).sum() for w, b in list(policy_layers) + list(value_layers))
+    if l2_outside_graph:
+        with torch.no_grad():
+            norms = torch.stack(torch._foreach_norm(flat_leaves(policy_layers, value_layers)))
+            l2 = l2_coef * 0.5 * (norms * norms).sum()
+    else:
+        l2 = l2_coef * 0.5 * sum((w ** 2).sum() + (b ** 2).sum() for w, b in list(policy_layers) + list(value_layers))
     total = policy_loss + v_loss + l2
     with torch.no_grad():
         a = data["raw_action"].long()
@@ -189,7 +198,7 @@ class ClipAdam:
         runs as multi-tensor operations -- a dozen launches for all leaves instead of eight
         per leaf; element by element the arithmetic is that of optax's clip + adam."""
         grads = list(grads)
-        gnorm = torch.sqrt(torch.stack([s.sum() for s in torch._foreach_mul(grads, grads)]).sum())
+        gnorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))  # optax.global_norm
         scale = torch.where(gnorm < self.max_norm, torch.ones_like(gnorm), self.max_norm / gnorm)
         lr = self.learning_rate()
         t = self.count + 1
@@ -235,25 +244,32 @@ def minibatch_step(policy_layers, value_layers, mean, std, data, optimizer, num_
     for p in leaves:
         p.requires_grad_(True)
     total, metrics = compute_muzero_loss(policy_layers, value_layers, mean, std, data, num_atoms,
-                                         **loss_kw)
+                                         l2_outside_graph=True, **loss_kw)
     grads = list(torch.autograd.grad(total, leaves))
     for p in leaves:
         p.requires_grad_(False)
+    # d/dp of l2_coef * 0.5 * p^2 (the same two-term sum per element as autograd's accumulation)
+    torch._foreach_add_(grads, leaves, alpha=loss_kw.get("l2_coef", 1e-4))
     allreduce_mean_(grads)
     optimizer.step(grads)
     return metrics
 
 
 def sgd_step(policy_layers, value_layers, mean, std, data, optimizer, num_atoms, num_minibatches,
-             generator=None, **loss_kw):
+             generator=None, rows=None, layout=None, **loss_kw):
     """alphazero.py:1074-1089: one permutation of the sampled batch, split into
-    `num_minibatches`, one optimiser update per minibatch."""
+    `num_minibatches`, one optimiser update per minibatch.
+    rows / layout (optional): the packed rows `data` was unpacked from (unpack_rows); they are
+    permuted once and the minibatches' fields are views of the result, instead of one gather
+    per field and minibatch."""
     n = next(iter(data.values())).shape[0]
     dev = next(iter(data.values())).device
     perm = torch.randperm(n, generator=generator, device=dev)
     metrics = []
-    for chunk in perm.reshape(num_minibatches, -1):
-        mb = {k: v[chunk] for k, v in data.items()}
+    if rows is not None:
+        shuffled = rows[perm].reshape(num_minibatches, -1, rows.shape[1])
+    for i, chunk in enumerate(perm.reshape(num_minibatches, -1)):
+        mb = unpack_rows(layout, shuffled[i]) if rows is not None else {k: v[chunk] for k, v in data.items()}
         metrics.append(minibatch_step(policy_layers, value_layers, mean, std, mb, optimizer,
                                       num_atoms, **loss_kw))
     return metrics

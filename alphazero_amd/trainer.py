@@ -215,7 +215,8 @@ class Trainer:
         for _ in range(cfg.update_epochs):
             metrics += L.sgd_step(self.policy_layers, self.value_layers, mean, std, batch,
                                   self.optimizer, cfg.num_atoms, cfg.num_minibatches,
-                                  generator=self._perm_gen, qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost,
+                                  generator=self._perm_gen, rows=rows, layout=self.layout,
+                                  qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost,
                                   l2_coef=cfg.l2_coef,
                                   per_importance_sampling=cfg.per_importance_sampling)
         # refresh the priorities of the sampled rows with the PRE-update networks (:1177-1180)
