@@ -192,17 +192,36 @@ class ClipAdam:
         frac = 1 - min(self.count, self.steps) / self.steps
         return (self.lr0 - self.end) * frac + self.end
 
+    def device_scalars(self, count):
+        """(learning rate, 1 - b1^t, 1 - b2^t) as float32 device scalars from `count`, a float64
+        device scalar holding the number of updates so far: the same double-precision expressions
+        as learning_rate() / step(), evaluated on the device so that a captured update needs
+        nothing from the host."""
+        t = count + 1
+        c1, c2 = 1 - self.b1 ** t, 1 - self.b2 ** t
+        if self.anneal:
+            frac = 1 - torch.clamp(count, max=float(self.steps)) / self.steps
+            lr = (self.lr0 - self.end) * frac + self.end
+        else:
+            lr = torch.full_like(count, self.lr0)
+        return lr.float(), c1.float(), c2.float()
+
     @torch.no_grad()
-    def step(self, grads):
+    def step(self, grads, scalars=None):
         """`grads`: one tensor per parameter leaf (views of one flat buffer are fine).  The update
         runs as multi-tensor operations -- a dozen launches for all leaves instead of eight
-        per leaf; element by element the arithmetic is that of optax's clip + adam."""
+        per leaf; element by element the arithmetic is that of optax's clip + adam.
+        scalars: device_scalars() of the update count (captured updates); the host's otherwise."""
         grads = list(grads)
         gnorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))  # optax.global_norm
         scale = torch.where(gnorm < self.max_norm, torch.ones_like(gnorm), self.max_norm / gnorm)
-        lr = self.learning_rate()
-        t = self.count + 1
-        c1, c2 = 1 - self.b1 ** t, 1 - self.b2 ** t
+        if scalars is None:
+            lr = self.learning_rate()
+            t = self.count + 1
+            c1, c2 = 1 - self.b1 ** t, 1 - self.b2 ** t
+            self.count += 1
+        else:
+            lr, c1, c2 = scalars
         g = torch._foreach_mul(grads, scale)
         torch._foreach_mul_(self.m, self.b1)
         torch._foreach_add_(self.m, g, alpha=1 - self.b1)
@@ -215,7 +234,6 @@ class ClipAdam:
         torch._foreach_add_(den, self.eps)
         torch._foreach_div_(upd, den)
         torch._foreach_sub_(self.params, upd)
-        self.count += 1
         return gnorm
 
 
@@ -255,13 +273,79 @@ def minibatch_step(policy_layers, value_layers, mean, std, data, optimizer, num_
     return metrics
 
 
+class GraphedMinibatchStep:
+    """minibatch_step for one process (no gradient all-reduce), captured once in a HIP graph and
+    replayed: the step is some three hundred launches of a few microseconds each, and replaying
+    them costs the host one call.  The minibatch's packed rows and the normaliser are copied into
+    fixed buffers before a replay; the optimiser's update count lives on the device (ClipAdam.
+    device_scalars), so nothing is read from the host inside the graph."""
+
+    METRICS = ("total_loss", "policy_loss", "value_loss", "l2_penalty", "entropy", "approx_kl")
+
+    def __init__(self, policy_layers, value_layers, optimizer, layout, n_rows, num_atoms, device, **loss_kw):
+        self.policy_layers, self.value_layers, self.optimizer = policy_layers, value_layers, optimizer
+        self.layout, self.num_atoms, self.loss_kw = layout, num_atoms, loss_kw
+        obs_dim = layout["observation"][1]
+        self.rows = torch.zeros((n_rows, layout["_width"]), device=device)
+        self.mean = torch.zeros(obs_dim, device=device)
+        self.std = torch.ones(obs_dim, device=device)
+        self.count = torch.full((), float(optimizer.count), dtype=torch.float64, device=device)
+        self.out = None
+        self.graph = None
+
+    def _body(self):
+        leaves = flat_leaves(self.policy_layers, self.value_layers)
+        for p in leaves:
+            p.requires_grad_(True)
+        total, metrics = compute_muzero_loss(self.policy_layers, self.value_layers, self.mean, self.std,
+                                             unpack_rows(self.layout, self.rows), self.num_atoms,
+                                             l2_outside_graph=True, **self.loss_kw)
+        grads = list(torch.autograd.grad(total, leaves))
+        for p in leaves:
+            p.requires_grad_(False)
+        with torch.no_grad():
+            torch._foreach_add_(grads, leaves, alpha=self.loss_kw.get("l2_coef", 1e-4))
+            self.optimizer.step(grads, scalars=self.optimizer.device_scalars(self.count))
+            self.count += 1
+            return torch.stack([metrics[k] for k in self.METRICS])
+
+    def _capture(self):
+        # (the state a warm-up run would change is put back before the capture)
+        saved = [t.clone() for t in self.optimizer.params + self.optimizer.m + self.optimizer.v] + [self.count.clone()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        for t, s in zip(self.optimizer.params + self.optimizer.m + self.optimizer.v + [self.count], saved):
+            t.copy_(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+        for t, s in zip(self.optimizer.params + self.optimizer.m + self.optimizer.v + [self.count], saved):
+            t.copy_(s)
+
+    def __call__(self, rows, mean, std):
+        self.rows.copy_(rows)
+        self.mean.copy_(mean)
+        self.std.copy_(std)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        self.optimizer.count += 1
+        out = self.out.clone()
+        return {k: out[i] for i, k in enumerate(self.METRICS)}
+
+
 def sgd_step(policy_layers, value_layers, mean, std, data, optimizer, num_atoms, num_minibatches,
-             generator=None, rows=None, layout=None, **loss_kw):
+             generator=None, rows=None, layout=None, graphed=None, **loss_kw):
     """alphazero.py:1074-1089: one permutation of the sampled batch, split into
     `num_minibatches`, one optimiser update per minibatch.
     rows / layout (optional): the packed rows `data` was unpacked from (unpack_rows); they are
     permuted once and the minibatches' fields are views of the result, instead of one gather
-    per field and minibatch."""
+    per field and minibatch.  graphed (optional, needs rows): a GraphedMinibatchStep that runs the
+    minibatches in place of minibatch_step."""
     n = next(iter(data.values())).shape[0]
     dev = next(iter(data.values())).device
     perm = torch.randperm(n, generator=generator, device=dev)
@@ -269,6 +353,9 @@ def sgd_step(policy_layers, value_layers, mean, std, data, optimizer, num_atoms,
     if rows is not None:
         shuffled = rows[perm].reshape(num_minibatches, -1, rows.shape[1])
     for i, chunk in enumerate(perm.reshape(num_minibatches, -1)):
+        if graphed is not None:
+            metrics.append(graphed(shuffled[i], mean, std))
+            continue
         mb = unpack_rows(layout, shuffled[i]) if rows is not None else {k: v[chunk] for k, v in data.items()}
         metrics.append(minibatch_step(policy_layers, value_layers, mean, std, mb, optimizer,
                                       num_atoms, **loss_kw))

@@ -65,6 +65,9 @@ class Config:
     # not in the reference: self-play evaluates the networks' hidden layers on the bfloat16 matrix
     # instructions (networks.FusedModel(hidden_bf16=True)); the learner stays float32
     selfplay_hidden_bf16: bool = False
+    # not in the reference: with one process the minibatch update (loss, gradient, clip + Adam)
+    # is captured once in a HIP graph and replayed (learner.GraphedMinibatchStep)
+    graph_sgd: bool = True
 
 
 class Trainer:
@@ -109,6 +112,7 @@ class Trainer:
         self.env_steps = 0
         self.trace = None   # a list here records every actor step's raw inputs and outputs
         self._perm_gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1)
+        self._graphed = None
 
     # -------------------------------------------------------------- self-play
     def _refresh_model(self):
@@ -212,10 +216,17 @@ class Trainer:
         self.buffer_state, rows = self.replay.sample(self.buffer_state)
         batch = L.unpack_rows(self.layout, rows)
         metrics = []
+        loss_kw = dict(qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost, l2_coef=cfg.l2_coef,
+                       per_importance_sampling=cfg.per_importance_sampling)
+        if cfg.graph_sgd and self.world == 1 and self.device.type == "cuda" and self._graphed is None:
+            self._graphed = L.GraphedMinibatchStep(
+                self.policy_layers, self.value_layers, self.optimizer, self.layout,
+                rows.shape[0] // cfg.num_minibatches, cfg.num_atoms, self.device, **loss_kw)
         for _ in range(cfg.update_epochs):
             metrics += L.sgd_step(self.policy_layers, self.value_layers, mean, std, batch,
                                   self.optimizer, cfg.num_atoms, cfg.num_minibatches,
                                   generator=self._perm_gen, rows=rows, layout=self.layout,
+                                  graphed=self._graphed,
                                   qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost,
                                   l2_coef=cfg.l2_coef,
                                   per_importance_sampling=cfg.per_importance_sampling)

@@ -282,3 +282,31 @@ def test_training_step_at_the_largest_configuration():
     assert all(math.isfinite(float(v)) for v in m.values()), m
     assert int(m["buffer_current_size"]) == 16384 and tr.env_steps == 16384
     assert float(tr.stats.count) == 16384
+
+
+@pytest.mark.parametrize("atoms,per_alpha", [(1, 0.0), (4, 0.6)])
+def test_graph_replayed_minibatch_updates_equal_the_eager_ones(atoms, per_alpha):
+    """Config.graph_sgd replays the captured minibatch update (loss, gradient, clip + Adam with the
+    update count and the learning-rate schedule on the device); two trainers from one seed, one
+    eager and one replaying, must hold the same parameters, moments and metrics after several
+    training steps (annealed learning rate, so the schedule matters)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd.trainer import Config, Trainer
+    kw = dict(env_id="CartPole-v1", num_envs=64, unroll_length=4, num_simulations=8, policy="gumbel",
+              num_atoms=atoms, per_alpha=per_alpha, max_replay_size=2048, min_replay_size=0,
+              replay_buffer_batch_size=32, num_minibatches=4, value_hidden=(64, 64), policy_hidden=(32, 32),
+              anneal_lr=True, total_timesteps=64 * 4 * 10)
+    eager, graphed = Trainer(Config(graph_sgd=False, **kw), device="cuda"), Trainer(Config(graph_sgd=True, **kw), device="cuda")
+    for _ in range(3):
+        me, mg = eager.training_step(), graphed.training_step()
+        for k in me:
+            torch.testing.assert_close(torch.as_tensor(mg[k]).float().cpu(), torch.as_tensor(me[k]).float().cpu(),
+                                       rtol=1e-5, atol=1e-7, msg=k)
+    assert graphed._graphed is not None and graphed._graphed.graph is not None and eager._graphed is None
+    assert eager.optimizer.count == graphed.optimizer.count == 12
+    assert float(graphed._graphed.count) == 12.0
+    for a, b in zip(eager.optimizer.params + eager.optimizer.m + eager.optimizer.v,
+                    graphed.optimizer.params + graphed.optimizer.m + graphed.optimizer.v):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-8)
