@@ -20,6 +20,7 @@ from .search import InjectedRecurrentFn, search
 from .seq_halving import get_sequence_of_considered_visits, get_table_of_considered_visits
 from .tree import SearchSummary, Tree, infer_batch_size
 from . import envs
+from . import minatar
 from . import replay_buffers
 
 __version__ = "0.1.0"
@@ -34,5 +35,5 @@ __all__ = [
     "qtransform_by_parent_and_siblings", "qtransform_completed_by_mix_value",
     "sampled_muzero_action_selection", "sampled_muzero_policy", "search",
     "ChanceRecurrentFnOutput", "DecisionRecurrentFnOutput", "StochasticRecurrentState",
-    "stochastic_muzero_policy",
+    "stochastic_muzero_policy", "minatar",
 ]

@@ -89,7 +89,9 @@ _I = C.c_int32
 _F = C.c_float
 _K2 = C.POINTER(C.c_uint32 * 2)
 
-# name -> (restype, argtypes); every symbol declared in include/az_mcts.h and az_replay.h
+BREAKOUT_WORDS, BREAKOUT_OBS, BREAKOUT_ACTIONS = 20, 400, 3   # include/az_minatar.h
+
+# name -> (restype, argtypes); every symbol declared in include/az_mcts.h, az_replay.h, az_minatar.h
 SIGNATURES = {
     "az_replay_partial_floats": (C.c_int64, [_I]),
     "az_replay_init": (C.c_int, [C.POINTER(Replay), C.POINTER(ReplayState), _P]),
@@ -136,6 +138,9 @@ SIGNATURES = {
     "az_actor_post": (C.c_int, [C.POINTER(SearchDesc), C.POINTER(TreePtrs), _P, _P, _I, _P, _P,
                                 _P, _P, _P]),
     "az_split_keys": (C.c_int, [_P, _I, _P, _P]),
+    "az_breakout_reset": (C.c_int, [_I, _P, _P, _P, _P, _P]),
+    "az_breakout_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "az_breakout_real_step": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "az_env_reset": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P]),
     "az_real_env_step": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "az_math_apply": (C.c_int, [_I, _I, _P, _P, _P]),

@@ -134,4 +134,7 @@ class Env:
 
 
 def make(env_id, **kwargs):
+    if env_id == "Breakout-MinAtar":   # alphazero.py:48; its own state layout and kernels
+        from . import minatar
+        return minatar.BreakoutEnv(**kwargs)
     return Env(env_id, **kwargs)

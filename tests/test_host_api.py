@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     declared = set()
-    for h in ("az_mcts.h", "az_replay.h"):
+    for h in ("az_mcts.h", "az_replay.h", "az_minatar.h"):
         header = open(os.path.join(ROOT, "include", h)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)   # comments mention other names
         declared |= set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", header))

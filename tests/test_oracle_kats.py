@@ -293,3 +293,80 @@ def test_select_only_trig_equals_the_early_return_forms(oracle):
     for sel, plain in (("sin_select", "sin"), ("cos_select", "cos")):
         a, b = oracle.math_apply(sel, x), oracle.math_apply(plain, x)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), sel
+
+
+# ---------------------------------------------------------------- MinAtar Breakout (hand-derived)
+def _breakout_state(**kw):
+    from oracle import minatar_numpy as bk
+    s = bk.EnvState()
+    s.brick_map[1:4, :] = 1
+    s.pos, s.ball_y, s.ball_x, s.ball_dir, s.last_y, s.last_x = 4, 3, 0, 2, 3, 0
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def test_breakout_known_answers():
+    """gymnax minatar/breakout.py worked by hand: directions 0..3 are up-left, up-right,
+    down-right, down-left (:183-194)."""
+    from oracle import minatar_numpy as bk
+    # free flight: down-right from (3, 0); the trail takes the old position; 'l' moves the paddle
+    obs, s, r, done, trunc = bk.step_env(_breakout_state(), 1)
+    assert (s.ball_y, s.ball_x, s.ball_dir, s.last_y, s.last_x, s.pos, s.time) == (4, 1, 2, 3, 0, 3, 1)
+    assert r == 0 and done == 0 and trunc == 0 and not s.strike
+    assert obs[9, 3, 0] == 1 and obs[4, 1, 1] == 1 and obs[3, 0, 2] == 1 and obs[:, :, 3].sum() == 30
+    # a brick: up-right from (4, 5) meets brick (3, 6): +1, the brick goes, the ball stays on its
+    # row, moves on in x and heads down-right (:230-244)
+    _, s, r, done, _ = bk.step_env(_breakout_state(ball_y=4, ball_x=5, ball_dir=1), 0)
+    assert r == 1 and s.brick_map[3, 6] == 0 and s.brick_map.sum() == 29
+    assert (s.ball_y, s.ball_x, s.ball_dir, s.strike) == (4, 6, 2, True)
+    # side wall: up-left from (5, 0) stays in column 0 and turns up-right (:196-204)
+    _, s, _, _, _ = bk.step_env(_breakout_state(ball_y=5, ball_x=0, ball_dir=0), 0)
+    assert (s.ball_y, s.ball_x, s.ball_dir) == (4, 0, 1)
+    # ceiling: up-right from (0, 4) over a cleared row 0 stays in row 0 and turns down-right (:223-228)
+    _, s, _, _, _ = bk.step_env(_breakout_state(ball_y=0, ball_x=4, ball_dir=1), 0)
+    assert (s.ball_y, s.ball_x, s.ball_dir) == (0, 5, 2)
+    # paddle under the ball's NEW column: down-right from (8, 3) with the paddle at 4 bounces back
+    # the way it came (:264-270: [2, 3, 0, 1])
+    _, s, _, done, _ = bk.step_env(_breakout_state(ball_y=8, ball_x=3, ball_dir=2, pos=4), 0)
+    assert (s.ball_y, s.ball_x, s.ball_dir, done) == (8, 4, 0, 0)
+    # paddle under the ball's OLD column: straight mirror (:257-262: [3, 2, 1, 0])
+    _, s, _, done, _ = bk.step_env(_breakout_state(ball_y=8, ball_x=3, ball_dir=2, pos=3), 0)
+    assert (s.ball_y, s.ball_x, s.ball_dir, done) == (8, 4, 1, 0)
+    # a miss ends the episode; the ball sits in the bottom row (:271-272)
+    _, s, _, done, _ = bk.step_env(_breakout_state(ball_y=8, ball_x=3, ball_dir=2, pos=0), 0)
+    assert done == 1 and s.terminal and (s.ball_y, s.ball_x) == (9, 4)
+    # the last brick gone: new rows appear when the ball next reaches the bottom row (:249-255)
+    empty = _breakout_state(ball_y=8, ball_x=3, ball_dir=2, pos=4)
+    empty.brick_map[:] = 0
+    _, s, _, _, _ = bk.step_env(empty, 0)
+    assert s.brick_map.sum() == 30
+    # time limit: truncation only when the step did not also end the game (:121-128)
+    _, s, _, done, trunc = bk.step_env(_breakout_state(time=999), 0)
+    assert done == 0 and trunc == 1
+    # the paddle stops at the walls (:171-178)
+    _, s, _, _, _ = bk.step_env(_breakout_state(pos=9), 2)
+    assert s.pos == 9
+    # packed form round trip
+    w = s.words()
+    assert bk.EnvState.from_words(w).words().tolist() == w.tolist() and w[11] == 0x3ff and w[10] == 0
+
+
+def test_breakout_reset_and_wrappers():
+    from oracle import minatar_numpy as bk
+    starts = set()
+    for seed in range(16):
+        s = bk.reset_env(np.array([0, seed], np.uint32))
+        assert (s.ball_y, s.pos, s.last_y, s.time, s.brick_map.sum()) == (3, 4, 3, 0, 30)
+        assert (s.ball_x, s.ball_dir) in ((0, 2), (9, 3)) and s.last_x == s.ball_x
+        starts.add(s.ball_x)
+    assert starts == {0, 9}
+    # EpisodeWrapper / AutoResetWrapper: an episode of 5 steps is cut and reset; the observation
+    # before the reset is kept in real_obs
+    w = bk.Wrapped((3, 4), episode_length=5)
+    for t in range(5):
+        w.step(0)
+    assert w.done == 1 and w.truncation == 1 and w.steps == 5 and w.state.time == 0
+    assert w.real_obs[:, :, 1].sum() == 1 and not np.array_equal(w.real_obs, w.obs)
+    w.step(0)
+    assert w.steps == 1 and w.done == 0

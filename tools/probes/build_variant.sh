@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../alphazero_amd/csrc"
 out=build_var_$tag
 mkdir -p $out
 FLAGS="--offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -fPIC -fno-fast-math -Wno-unused-function -Wno-pass-failed -DAZ_NARROW_BUILD $*"
-for f in az_api az_search az_fused az_replay; do
+for f in az_api az_search az_fused az_replay az_minatar; do
   /opt/rocm/bin/hipcc $FLAGS -c -o $out/$f.o $f.hip &
 done
 wait
