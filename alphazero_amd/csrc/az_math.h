@@ -52,6 +52,41 @@ AZ_HD float az_u2f(uint32_t u) {
 }
 AZ_HD float az_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 AZ_HD float az_sqrtf(float x) { return __builtin_sqrtf(x); }
+
+// Summation order of the dense layers (part of the numerics specification: a float32 dot
+// product depends on it, and the reference's `jnp.dot` fixes none).  Every output is a chain of
+// fused multiply-adds over the inputs in index order, then the bias -- except the SMALL OUTPUT
+// HEADS: when the deeper network's last layer (or both networks' last layers, if they are equally
+// deep) has at most 16 outputs, at most 8 outputs in all and at most 1024 words of weights and
+// biases (inputs padded to a multiple of 16, plus 16 bias words per head), each of its outputs
+// is the sum of FOUR interleaved chains, chain g over the inputs k = g, g + 4, g + 8, ... in
+// order, combined as (c0 + c1) + (c2 + c3), then the bias.  (A 256-long chain for a single value
+// output is the critical path of every network evaluation otherwise; four chains of 64 are not.)
+// Returns bit 0: the policy network's last layer is such a head, bit 1: the value network's.
+AZ_HD int az_small_heads(int pol_layers, int pol_in, int pol_out, int val_layers, int val_in, int val_out) {
+  const int P = pol_layers > val_layers ? pol_layers : val_layers;
+  if (P < 2) return 0;
+  int total = 0, items = 0, mask = 0;
+  if (pol_layers == P) {
+    if (pol_out > 16) return 0;
+    total += pol_out * ((pol_in + 15) / 16 * 16) + 16;
+    items += pol_out;
+    mask |= 1;
+  }
+  if (val_layers == P) {
+    if (val_out > 16) return 0;
+    total += val_out * ((val_in + 15) / 16 * 16) + 16;
+    items += val_out;
+    mask |= 2;
+  }
+  return total <= 1024 && items <= 8 ? mask : 0;
+}
+// One output of a small head: x[k], w[k * w_stride] for k < n.
+AZ_HD float az_head_dot(const float* x, const float* w, int w_stride, int n) {
+  float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k = 0; k < n; ++k) c[k & 3] = __builtin_fmaf(x[k], w[(size_t)k * w_stride], c[k & 3]);
+  return (c[0] + c[1]) + (c[2] + c[3]);
+}
 AZ_HD int az_isnan(float x) { return x != x; }
 /* jnp.maximum / jnp.minimum propagate NaN. */
 AZ_HD float az_maxf(float a, float b) {

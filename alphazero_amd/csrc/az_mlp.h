@@ -323,19 +323,18 @@ __host__ __device__ inline int az_mlp_phases(const ModelDev& md) {
 // instead, one wave per output column (az_mlp_heads), from weights staged once per kernel in
 // LDS, and the unit machinery covers the phases before it.  Per head: nout columns of kp
 // weights + 16 biases.
-#define AZ_HEAD_MAX_FLOATS 1024
+// Which layers these are is part of the numerics specification (az_small_heads, az_math.h: they
+// are summed as four interleaved chains); this function only sizes their LDS copy.
 __host__ __device__ inline int az_mlp_head_floats(const ModelDev& md) {
   const int P = az_mlp_phases(md);
-  if (P < 2) return 0;
-  int total = 0, items = 0;
-  for (int net = 0; net < 2; ++net) {
-    const MlpLayout& L = net ? md.val : md.pol;
-    if (L.n_layers < P) continue;
-    if (L.np[P - 1] != 16) return 0;
-    total += L.nout[P - 1] * L.kp[P - 1] + 16;
-    items += L.nout[P - 1];
-  }
-  return total <= AZ_HEAD_MAX_FLOATS && items <= AZ_MLP_WAVES ? total : 0;
+  const int lp = md.pol.n_layers, lv = md.val.n_layers;
+  const int mask = az_small_heads(lp, lp > 0 ? md.pol.kin[lp - 1] : 0, lp > 0 ? md.pol.nout[lp - 1] : 0,
+                                  lv, lv > 0 ? md.val.kin[lv - 1] : 0, lv > 0 ? md.val.nout[lv - 1] : 0);
+  int total = 0;
+  if (mask & 1) total += md.pol.nout[P - 1] * md.pol.kp[P - 1] + 16;
+  if (mask & 2) total += md.val.nout[P - 1] * md.val.kp[P - 1] + 16;
+  static_assert(AZ_MLP_WAVES == 8, "az_small_heads allows one output column per wave");
+  return total;
 }
 __host__ __device__ inline bool az_mlp_heads_apply(const ModelDev& md) { return md.head_floats > 0; }
 // phases that run as units of the matrix pipe
@@ -779,79 +778,42 @@ AZ_DEV void az_mlp_stage_heads(const ModelDev& md, const MlpLds& s, int tid, int
   }
 }
 
-// One column of an output head on the vector ALU: the wave's lanes own the 16 rows (lane & 15;
-// all 64 lanes run, which a lone wave does faster than 16 of them) and run each element's
-// k-ordered chain of fused multiply-adds -- the operations, in the order, of the matrix
-// instruction that would otherwise compute it.  Activations and staged weights are in the same
-// permuted order: one 16-byte read at m * kp / 4 + 4 kb holds k = 16 kb + m + {0, 4, 8, 12}, four
-// of each cover a k-block.  With the width known at compile time (KP > 0) every read is the
-// lane's base address plus an immediate; the loop then consists of reads and the chain only,
-// which is what bounds a lone wave: it issues one instruction per 4 to 6 cycles.
+// One column of an output head on the vector ALU, in the order of az_head_dot (az_math.h): the
+// wave's lanes own the 16 rows (lane & 15), and each of the four groups of 16 lanes runs ONE of
+// the four interleaved chains -- chain g = lane >> 4 over the inputs k = g, g + 4, ... in order --
+// before two lane exchanges add them up as (c0 + c1) + (c2 + c3) (floating-point addition is
+// commutative, so every group ends with the same bits).  Activations and staged weights are in
+// the same permuted order, plane k & 3 holding its elements k >> 2 side by side: a chain reads
+// its plane front to back, 16 bytes at a time.
 template <int KP>
-AZ_DEV float az_mlp_head_chain(const float* arow, const float* wcol, int kp_runtime) {
-  const int kp = KP > 0 ? KP : kp_runtime, kpq = kp >> 2, nkb = kp >> 4;
-  struct Blk {
-    az_f32x4 a0, a1, a2, a3, w0, w1, w2, w3;
-  };
-  auto read_blk = [&](int kb) {
-    Blk b;
-    b.a0 = *reinterpret_cast<const az_f32x4*>(arow + 4 * kb);
-    b.a1 = *reinterpret_cast<const az_f32x4*>(arow + kpq + 4 * kb);
-    b.a2 = *reinterpret_cast<const az_f32x4*>(arow + 2 * kpq + 4 * kb);
-    b.a3 = *reinterpret_cast<const az_f32x4*>(arow + 3 * kpq + 4 * kb);
-    b.w0 = *reinterpret_cast<const az_f32x4*>(wcol + 4 * kb);
-    b.w1 = *reinterpret_cast<const az_f32x4*>(wcol + kpq + 4 * kb);
-    b.w2 = *reinterpret_cast<const az_f32x4*>(wcol + 2 * kpq + 4 * kb);
-    b.w3 = *reinterpret_cast<const az_f32x4*>(wcol + 3 * kpq + 4 * kb);
-    return b;
-  };
+AZ_DEV float az_mlp_head_chain(const float* arow, const float* wcol, int kp_runtime, int lane) {
+  const int kp = KP > 0 ? KP : kp_runtime, kpq = kp >> 2;
+  const float* a = arow + (lane >> 4) * kpq;
+  const float* w = wcol + (lane >> 4) * kpq;
   float acc = 0.0f;
-#define AZ_HEAD_STEP(B, c)                     \
-  acc = __builtin_fmaf(B.a0.c, B.w0.c, acc);   \
-  acc = __builtin_fmaf(B.a1.c, B.w1.c, acc);   \
-  acc = __builtin_fmaf(B.a2.c, B.w2.c, acc);   \
-  acc = __builtin_fmaf(B.a3.c, B.w3.c, acc)
-#define AZ_HEAD_BLOCK(B) \
-  AZ_HEAD_STEP(B, x);    \
-  AZ_HEAD_STEP(B, y);    \
-  AZ_HEAD_STEP(B, z);    \
-  AZ_HEAD_STEP(B, w)
-  // Two k-blocks per turn, each read while the other is multiplied (the fences keep the
-  // compiler from folding the halves back into read-wait-multiply); whole pairs without a
-  // branch inside: a conditional chain would draw the reads issued before it into its own arm.
-  Blk even = read_blk(0);
-  int kb = 0;
+  az_f32x4 a4 = *reinterpret_cast<const az_f32x4*>(a), w4 = *reinterpret_cast<const az_f32x4*>(w);
+  auto body = [&](int i) {
+    // (the next four elements are requested before these four are multiplied; the last turn
+    // reads its own block again.  Requesting more ahead -- all operands, or groups of four
+    // blocks -- was measured: the phase gets no shorter and the fused kernel starts to spill)
+    const int nx = i + 4 < kpq ? i + 4 : i;
+    const az_f32x4 an = *reinterpret_cast<const az_f32x4*>(a + nx), wn = *reinterpret_cast<const az_f32x4*>(w + nx);
+    acc = __builtin_fmaf(a4.x, w4.x, acc);
+    acc = __builtin_fmaf(a4.y, w4.y, acc);
+    acc = __builtin_fmaf(a4.z, w4.z, acc);
+    acc = __builtin_fmaf(a4.w, w4.w, acc);
+    a4 = an;
+    w4 = wn;
+  };
   if constexpr (KP > 0) {
 #pragma unroll
-    for (; kb + 2 <= nkb; kb += 2) {
-      const Blk odd = read_blk(kb + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      AZ_HEAD_BLOCK(even);
-      __builtin_amdgcn_sched_barrier(0);
-      even = read_blk(kb + 2 < nkb ? kb + 2 : kb);
-      __builtin_amdgcn_sched_barrier(0);
-      AZ_HEAD_BLOCK(odd);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int i = 0; i < KP / 4; i += 4) body(i);
   } else {
 #pragma unroll 1
-    for (; kb + 2 <= nkb; kb += 2) {
-      const Blk odd = read_blk(kb + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      AZ_HEAD_BLOCK(even);
-      __builtin_amdgcn_sched_barrier(0);
-      even = read_blk(kb + 2 < nkb ? kb + 2 : kb);
-      __builtin_amdgcn_sched_barrier(0);
-      AZ_HEAD_BLOCK(odd);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int i = 0; i < kpq; i += 4) body(i);
   }
-  if (kb < nkb) {
-    AZ_HEAD_BLOCK(even);
-  }
-#undef AZ_HEAD_BLOCK
-#undef AZ_HEAD_STEP
-  return acc;
+  const float pair = acc + __shfl_xor(acc, 16);
+  return pair + __shfl_xor(pair, 32);
 }
 
 // The output heads of the last phase on the vector ALU (az_mlp_heads_apply): every output column
@@ -872,10 +834,10 @@ AZ_DEV void az_mlp_heads(const ModelDev& md, const MlpLds& s, int wave, int lane
     const float* arow = s.base + (is_val ? in_v : in_p) + row * (is_val ? s.vstride : s.pstride);
     const float* head = s.head_w + (is_val && has_p ? nout_p * kp_p + 16 : 0);
     const float* wcol = head + col * kp;
-    const float acc = kp == 256  ? az_mlp_head_chain<256>(arow, wcol, kp)
-                      : kp == 128 ? az_mlp_head_chain<128>(arow, wcol, kp)
-                      : kp == 64  ? az_mlp_head_chain<64>(arow, wcol, kp)
-                                  : az_mlp_head_chain<0>(arow, wcol, kp);
+    const float acc = kp == 256  ? az_mlp_head_chain<256>(arow, wcol, kp, lane)
+                      : kp == 128 ? az_mlp_head_chain<128>(arow, wcol, kp, lane)
+                      : kp == 64  ? az_mlp_head_chain<64>(arow, wcol, kp, lane)
+                                  : az_mlp_head_chain<0>(arow, wcol, kp, lane);
     const float bias = head[(is_val ? nout_v : nout_p) * kp + col];
     if (lane < 16) s.base[(is_val ? out_v + row * AZ_MAX_ATOMS : out_p + row * AZ_MAX_ACTIONS) + col] = acc + bias;
   }

@@ -716,7 +716,10 @@ void oz_env_reset(int env_id, int B, const uint32_t* keys, float* state, int32_t
 /* networks (networks/networks.py:25-48, 153-193; alphazero.py:208-216;  */
 /* running_statistics.py:183-199)                                        */
 
-static void oz_mlp_forward_one(const oz_mlp* m, const float* x, float* out) {
+/* networks/networks.py:25-48.  The summation order of a layer is a choice of this build's numerics
+ * specification (az_math.h): a chain of fused multiply-adds over the inputs in index order, or,
+ * for a small output head (`small_head`, az_small_heads), four interleaved chains. */
+static void oz_mlp_forward_one(const oz_mlp* m, const float* x, float* out, int small_head) {
   float bufa[2048], bufb[2048];
   const float* h = x;
   float* dst = bufa;
@@ -725,7 +728,10 @@ static void oz_mlp_forward_one(const oz_mlp* m, const float* x, float* out) {
     float* y = (L == m->n_layers - 1) ? out : dst;
     for (int n = 0; n < on; ++n) {
       float acc = 0.0f;
-      for (int k = 0; k < in; ++k) acc = az_fmaf(h[k], m->w[L][(size_t)k * on + n], acc);
+      if (small_head && L == m->n_layers - 1)
+        acc = az_head_dot(h, m->w[L] + n, on, in);
+      else
+        for (int k = 0; k < in; ++k) acc = az_fmaf(h[k], m->w[L][(size_t)k * on + n], acc);
       acc = acc + m->b[L][n];
       if (L != m->n_layers - 1) acc = az_swish(acc);
       y[n] = acc;
@@ -739,8 +745,11 @@ static void oz_forward_one(const oz_model* md, const float* obs, float* logits, 
   float x[8];
   int od = oz_obs_dim(md->env_id);
   for (int i = 0; i < od; ++i) x[i] = (obs[i] - md->norm_mean[i]) / md->norm_std[i];
-  oz_mlp_forward_one(&md->policy, x, logits);
-  oz_mlp_forward_one(&md->value, x, value);
+  const oz_mlp *p = &md->policy, *v = &md->value;
+  const int heads = az_small_heads(p->n_layers, p->sizes[p->n_layers - 1], p->sizes[p->n_layers],
+                                   v->n_layers, v->sizes[v->n_layers - 1], v->sizes[v->n_layers]);
+  oz_mlp_forward_one(p, x, logits, heads & 1);
+  oz_mlp_forward_one(v, x, value, heads & 2);
 }
 
 void oz_forward(const oz_model* md, int B, const float* obs, float* logits, float* value) {

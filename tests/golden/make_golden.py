@@ -4,6 +4,10 @@ The reference itself cannot be run in the build environment (its JAX runtime is
 not installable), so these vectors freeze the CPU checker's outputs -- which the
 hand-derived known-answer tests pin -- rather than outputs of the reference.
 Run from the repository root:  python tests/golden/make_golden.py
+
+The `cartpole_gumbel` case runs networks, so its float arrays follow the numerics specification's
+summation order (alphazero_amd/csrc/az_math.h); it was regenerated when small output heads became
+four interleaved chains (last-bit changes in four float arrays, no discrete output moved).
 """
 import os
 import sys
