@@ -449,8 +449,9 @@ AZ_DEV void az_mlp_tile_epilogue(const MlpTile& o, int n_off, const az_f32x4& ac
   const int n = o.n0 + n_off + (lane & 15);
   float* out = lds_base + o.out_off + (lane >> 4) * 4 * o.out_stride;
   if (o.act) {
-    const az_f32x2 lo = az_swish2(az_f32x2{acc.x, acc.y} + az_splat2(bn));
-    const az_f32x2 hi = az_swish2(az_f32x2{acc.z, acc.w} + az_splat2(bn));
+    az_f32x2 v[2] = {az_f32x2{acc.x, acc.y} + az_splat2(bn), az_f32x2{acc.z, acc.w} + az_splat2(bn)};
+    az_swish2xn<2>(v);
+    const az_f32x2 lo = v[0], hi = v[1];
     float* q = out + az_act_index(n, o.out_np);
     q[0] = lo.x;
     q[o.out_stride] = lo.y;

@@ -66,12 +66,24 @@ AZ_DEV az_f32x2 az_swish2(az_f32x2 x) { return x * az_rcp2_exact(az_one_plus_exp
 // instead of at the latency of one dependent chain.  The empty asm after each step keeps
 // the order (left alone, the scheduler -- short of registers next to the weight slots --
 // runs the chains nearly one after the other).  Same operations per element as az_swish2.
+// N = 2: the two pairs of a single tile (a rider's), which otherwise run one after the other.
+// (Six at once -- a rider's two with the pair's four -- was measured: the fused kernel spills
+// three registers and gets 2 % slower.)
+template <int N>
+AZ_DEV void az_sw_keep(az_f32x2 (&a)[N]) {
+  if constexpr (N == 4)
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+  else
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+}
 #define AZ_SW4(arr, expr)                                         \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) arr[i] = (expr); \
-  asm volatile("" : "+v"(arr[0]), "+v"(arr[1]), "+v"(arr[2]), "+v"(arr[3]))
-AZ_DEV void az_swish2x4(az_f32x2 (&x)[4]) {
+  _Pragma("unroll") for (int i = 0; i < N; ++i) arr[i] = (expr); \
+  az_sw_keep<N>(arr)
+template <int N>
+AZ_DEV void az_swish2xn(az_f32x2 (&x)[N]) {
+  static_assert(N == 4 || N == 2, "four or two pairs");
   const az_f32x2 one = az_splat2(1.0f);
-  az_f32x2 t[4], m[4], kf[4], r[4], rr[4], p[4], sc[4], d[4], y[4], e[4], q[4];
+  az_f32x2 t[N], m[N], kf[N], r[N], rr[N], p[N], sc[N], d[N], y[N], e[N], q[N];
   // 1 + exp(t), as in az_one_plus_exp_neg2
   AZ_SW4(t, (az_f32x2{__builtin_amdgcn_fmed3f(-x[i].x, -64.0f, 64.0f), __builtin_amdgcn_fmed3f(-x[i].y, -64.0f, 64.0f)}));
   AZ_SW4(m, t[i] * az_splat2(1.44269502162933349609375f));
@@ -101,5 +113,6 @@ AZ_DEV void az_swish2x4(az_f32x2 (&x)[4]) {
   AZ_SW4(x, x[i] * q[i]);
 }
 #undef AZ_SW4
+AZ_DEV void az_swish2x4(az_f32x2 (&x)[4]) { az_swish2xn<4>(x); }
 
 #endif  // AZ_SWISH_H_
