@@ -103,14 +103,29 @@ AZ_DEV float az_scan_value(const az_replay& r, int i, int n_valid, int head, con
   return v;
 }
 
-// The run of AZ_SCAN_T values of thread t in chunk k: inclusive sums left to right.
+// A chunk's values pass through LDS: a thread's run is AZ_SCAN_T CONSECUTIVE rows, which read
+// straight from memory is 64 separate lines per wave access; staged, the workgroup fetches whole
+// lines (thread t takes rows t, t + 256, ...) and every thread then picks its run out of LDS.
+// Element x of the chunk sits at x + x / AZ_SCAN_T, so that the threads' runs start in
+// different banks.
+#define AZ_SCAN_STAGE (AZ_SCAN_CHUNK + AZ_SCAN_CHUNK / AZ_SCAN_T)
+AZ_DEV int az_stage_index(int x) { return x + x / AZ_SCAN_T; }
+
+// The run of AZ_SCAN_T values of thread t in chunk k: inclusive sums left to right.  `vals`
+// (AZ_SCAN_STAGE floats of LDS) keeps the chunk's values for the caller.  Workgroup-wide call.
 AZ_DEV void az_scan_run(const az_replay& r, int chunk, int t, int n_valid, int head,
-                        const float* divisor, float (&incl)[AZ_SCAN_T]) {
-  const int base = chunk * AZ_SCAN_CHUNK + t * AZ_SCAN_T;
+                        const float* divisor, float (&incl)[AZ_SCAN_T], float* vals) {
+  const int chunk_base = chunk * AZ_SCAN_CHUNK;
+#pragma unroll
+  for (int k = 0; k < AZ_SCAN_T; ++k) {
+    const int x = k * AZ_SCAN_B + t;
+    vals[az_stage_index(x)] = az_scan_value(r, chunk_base + x, n_valid, head, divisor);
+  }
+  __syncthreads();
   float s = 0.0f;
 #pragma unroll
   for (int j = 0; j < AZ_SCAN_T; ++j) {
-    const float v = az_scan_value(r, base + j, n_valid, head, divisor);
+    const float v = vals[az_stage_index(t * AZ_SCAN_T + j)];
     s = j == 0 ? v : s + v;
     incl[j] = s;
   }
@@ -121,10 +136,21 @@ AZ_DEV void az_scan_run(const az_replay& r, int chunk, int t, int n_valid, int h
 AZ_DEV float az_scan_runs(float* tot, float* off, int t) {
   __syncthreads();
   if (t == 0) {
+    // (sixteen totals are fetched ahead of their sixteen dependent additions: one LDS round trip
+    // per addition made this loop three quarters of the scan kernels' time)
     float s = 0.0f;
-    for (int i = 0; i < AZ_SCAN_B; ++i) {
-      off[i] = s;
-      s = s + tot[i];
+#pragma unroll 1
+    for (int i = 0; i < AZ_SCAN_B; i += 16) {
+      float v[16], o[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = tot[i + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        o[j] = s;
+        s = s + v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) off[i + j] = o[j];
     }
     // chunk total as the contract defines it: last run offset + last run total
     tot[AZ_SCAN_B] = off[AZ_SCAN_B - 1] + tot[AZ_SCAN_B - 1];
@@ -133,13 +159,40 @@ AZ_DEV float az_scan_runs(float* tot, float* off, int t) {
   return off[t];
 }
 
+// The offset of chunk `chunk`: the chunk totals before it added up left to right (the contract's
+// order) by one thread of the workgroup, out of a copy in LDS that all threads fetch at once.  For
+// up to AZ_CHUNKS_IN_KERNEL chunks this replaces a launch of its own (k_scan_chunks) in front of
+// every consumer; `stage` holds AZ_CHUNKS_IN_KERNEL floats.
+#define AZ_CHUNKS_IN_KERNEL 1024
+AZ_DEV float az_chunk_offset(const float* __restrict__ chunk_tot, int chunk, float* stage, int t, int nthreads) {
+  for (int i = t; i < chunk; i += nthreads) stage[i] = chunk_tot[i];
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.0f;
+    int i = 0;
+#pragma unroll 1
+    for (; i + 16 <= chunk; i += 16) {  // (operands fetched sixteen at a time, as in az_scan_runs)
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = stage[i + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s = s + v[j];
+    }
+    for (; i < chunk; ++i) s = s + stage[i];
+    stage[AZ_CHUNKS_IN_KERNEL] = s;
+  }
+  __syncthreads();
+  return stage[AZ_CHUNKS_IN_KERNEL];
+}
+
 // pass A: chunk totals
 __global__ __launch_bounds__(AZ_SCAN_B) void k_scan_totals(az_replay r, int n_valid, int head,
                                                            const float* divisor,
                                                            float* __restrict__ chunk_tot) {
-  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+  __shared__ __attribute__((aligned(16))) float tot[AZ_SCAN_B + 4], off[AZ_SCAN_B];
+  __shared__ float vals[AZ_SCAN_STAGE];
   float incl[AZ_SCAN_T];
-  az_scan_run(r, blockIdx.x, threadIdx.x, n_valid, head, divisor, incl);
+  az_scan_run(r, blockIdx.x, threadIdx.x, n_valid, head, divisor, incl, vals);
   tot[threadIdx.x] = incl[AZ_SCAN_T - 1];
   az_scan_runs(tot, off, threadIdx.x);
   if (threadIdx.x == 0) chunk_tot[blockIdx.x] = tot[AZ_SCAN_B];
@@ -158,32 +211,59 @@ __global__ void k_scan_chunks(const float* __restrict__ chunk_tot, int nchunks,
   }
 }
 
+#ifdef AZ_STAMP
+// Diagnostic build only: cycle stamps of the last workgroup of k_scan_final.
+__device__ long long az_replay_stamps[16];
+#define AZ_RSTAMP(k) \
+  do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) az_replay_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int az_debug_read_replay_stamps(long long* host_out) {
+  AZ_HIP(hipDeviceSynchronize());
+  AZ_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(az_replay_stamps), sizeof(long long) * 16));
+  return AZ_OK;
+}
+#else
+#define AZ_RSTAMP(k) do { } while (0)
+#endif
+
 // pass B: cum[i] = (chunk_off + run_off) + incl; optionally the importance weights
 // 1 / (n_valid * p + 1e-10)^beta of every row with their maximum (as uint bits: the
 // weights are positive), replay_buffers.py:329-330.
 __global__ __launch_bounds__(AZ_SCAN_B) void k_scan_final(az_replay r, int n_valid, int head,
                                                           const float* divisor,
                                                           const float* __restrict__ chunk_off,
+                                                          const float* __restrict__ chunk_tot,
                                                           float* __restrict__ cum, int with_weights,
                                                           float beta, unsigned int* wmax_bits) {
-  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+  __shared__ __attribute__((aligned(16))) float tot[AZ_SCAN_B + 4], off[AZ_SCAN_B];
+  __shared__ __attribute__((aligned(16))) float stage[AZ_CHUNKS_IN_KERNEL + 4];
+  __shared__ float vals[AZ_SCAN_STAGE], cums[AZ_SCAN_STAGE];
   __shared__ unsigned int smax;
   float incl[AZ_SCAN_T];
   const int t = threadIdx.x;
   if (t == 0) smax = 0u;
-  az_scan_run(r, blockIdx.x, t, n_valid, head, divisor, incl);
+  AZ_RSTAMP(0);
+  az_scan_run(r, blockIdx.x, t, n_valid, head, divisor, incl, vals);
+  AZ_RSTAMP(1);
   tot[t] = incl[AZ_SCAN_T - 1];
   const float run_off = az_scan_runs(tot, off, t);
-  const float base_off = chunk_off[blockIdx.x] + run_off;
-  const int base = blockIdx.x * AZ_SCAN_CHUNK + t * AZ_SCAN_T;
+  AZ_RSTAMP(2);
+  // (chunk_tot != null: the chunk totals; the offsets are worked out here)
+  const float c_off = chunk_tot ? az_chunk_offset(chunk_tot, blockIdx.x, stage, t, AZ_SCAN_B) : chunk_off[blockIdx.x];
+  AZ_RSTAMP(3);
+  const float base_off = c_off + run_off;
+#pragma unroll
+  for (int j = 0; j < AZ_SCAN_T; ++j) cums[az_stage_index(t * AZ_SCAN_T + j)] = base_off + incl[j];
+  __syncthreads();
+  AZ_RSTAMP(4);
+  // out through LDS again: whole lines of cum and of the weights
   unsigned int mx = 0u;
 #pragma unroll
-  for (int j = 0; j < AZ_SCAN_T; ++j) {
-    const int i = base + j;
+  for (int k = 0; k < AZ_SCAN_T; ++k) {
+    const int x = k * AZ_SCAN_B + t, i = blockIdx.x * AZ_SCAN_CHUNK + x;
     if (i < r.cap) {
-      cum[i] = base_off + incl[j];
+      cum[i] = cums[az_stage_index(x)];
       if (with_weights) {
-        const float p = az_scan_value(r, i, n_valid, head, divisor);
+        const float p = vals[az_stage_index(x)];
         const float w = 1.0f / az_powf((float)n_valid * p + 1e-10f, beta);
         r.weight[az_phys(i, head, r.cap)] = w;
         const unsigned int b = az_f2u(w);
@@ -191,11 +271,20 @@ __global__ __launch_bounds__(AZ_SCAN_B) void k_scan_final(az_replay r, int n_val
       }
     }
   }
+  AZ_RSTAMP(5);
   if (with_weights) {
-    atomicMax(&smax, mx);
+    // wave maximum first, then one LDS atomic per wave and one global atomic per workgroup, none
+    // of which hands a value back (a returning global atomic is a 2 us round trip at the very end
+    // of every workgroup)
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned int other = (unsigned int)__shfl_xor((int)mx, o);
+      mx = other > mx ? other : mx;
+    }
+    if ((t & 63) == 0) __hip_atomic_fetch_max(&smax, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    if (t == 0) atomicMax(wmax_bits, smax);
+    if (t == 0) __hip_atomic_fetch_max(wmax_bits, smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  AZ_RSTAMP(6);
 }
 
 __global__ void k_weights_normalise(az_replay r, const unsigned int* __restrict__ wmax_bits) {
@@ -215,12 +304,15 @@ static int az_scan_launch(const az_replay* r, const az_replay_state* st, const f
   k_scan_totals<<<dim3(nc), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, divisor,
                                                       chunk_tot);
   AZ_LAUNCH_CHECK();
-  k_scan_chunks<<<dim3(1), dim3(64), 0, s>>>(chunk_tot, nc, chunk_off);
-  AZ_LAUNCH_CHECK();
+  const bool in_kernel = nc <= AZ_CHUNKS_IN_KERNEL;  // the consumers add the chunk totals up themselves
+  if (!in_kernel) {
+    k_scan_chunks<<<dim3(1), dim3(64), 0, s>>>(chunk_tot, nc, chunk_off);
+    AZ_LAUNCH_CHECK();
+  }
   if (need_cum) {
     k_scan_final<<<dim3(nc), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, divisor,
-                                                       chunk_off, r->cum, with_weights, beta,
-                                                       wmax_bits);
+                                                       chunk_off, in_kernel ? chunk_tot : nullptr, r->cum,
+                                                       with_weights, beta, wmax_bits);
     AZ_LAUNCH_CHECK();
   }
   return AZ_OK;
@@ -228,18 +320,25 @@ static int az_scan_launch(const az_replay* r, const az_replay_state* st, const f
 
 // total[0] = cum[cap - 1] of the scan whose chunk totals / offsets are in `partial`:
 // the last row's formula needs its run, so it is recomputed by one workgroup.
+// chunk_tot != null: the chunk totals, from which the last chunk's offset is worked out here.
+// zero_word (or null): a word set to zero on the way (the weights' running maximum).
 __global__ __launch_bounds__(AZ_SCAN_B) void k_scan_last(az_replay r, int n_valid, int head,
                                                          const float* divisor,
                                                          const float* __restrict__ chunk_off,
-                                                         float* __restrict__ total) {
-  __shared__ float tot[AZ_SCAN_B + 1], off[AZ_SCAN_B];
+                                                         const float* __restrict__ chunk_tot,
+                                                         float* __restrict__ total, unsigned int* zero_word) {
+  __shared__ __attribute__((aligned(16))) float tot[AZ_SCAN_B + 4], off[AZ_SCAN_B];
+  __shared__ __attribute__((aligned(16))) float stage[AZ_CHUNKS_IN_KERNEL + 4];
+  __shared__ float vals[AZ_SCAN_STAGE];
   float incl[AZ_SCAN_T];
   const int chunk = (r.cap - 1) / AZ_SCAN_CHUNK, t = threadIdx.x;
-  az_scan_run(r, chunk, t, n_valid, head, divisor, incl);
+  az_scan_run(r, chunk, t, n_valid, head, divisor, incl, vals);
   tot[t] = incl[AZ_SCAN_T - 1];
   const float run_off = az_scan_runs(tot, off, t);
+  const float c_off = chunk_tot ? az_chunk_offset(chunk_tot, chunk, stage, t, AZ_SCAN_B) : chunk_off[chunk];
   const int within = (r.cap - 1) - chunk * AZ_SCAN_CHUNK;
-  if (t == within / AZ_SCAN_T) total[0] = (chunk_off[chunk] + run_off) + incl[within % AZ_SCAN_T];
+  if (t == within / AZ_SCAN_T) total[0] = (c_off + run_off) + incl[within % AZ_SCAN_T];
+  if (t == 0 && zero_word) *zero_word = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -291,6 +390,34 @@ __global__ void k_replay_gather(az_replay r, int head, const int32_t* __restrict
   }
 }
 
+// k_draw_prioritized and k_weights_normalise in one launch: both only need the finished prefix
+// sums / weight maximum, neither reads what the other writes.  The first `draw_blocks`
+// workgroups draw, the others normalise.
+__global__ __launch_bounds__(256) void k_draw_and_normalise(az_replay r, uint32_t k0, uint32_t k1, int bs,
+                                                            int32_t* __restrict__ out_idx, int draw_blocks,
+                                                            const unsigned int* __restrict__ wmax_bits) {
+  if ((int)blockIdx.x < draw_blocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs) return;
+    const float u = az_uniform_from_bits(az_random_bits32(k0, k1, (uint32_t)i), 0.0f, 1.0f);
+    const float target = r.cum[r.cap - 1] * (1.0f - u);
+    int lo = 0, hi = r.cap;  // first index with cum[index] >= target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (r.cum[mid] < target)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    out_idx[i] = lo;
+    return;
+  }
+  const float wmax = az_u2f(*wmax_bits);
+  const int nb = gridDim.x - draw_blocks;
+  for (int i = (blockIdx.x - draw_blocks) * blockDim.x + threadIdx.x; i < r.cap; i += nb * blockDim.x)
+    r.weight[i] = r.weight[i] / wmax;
+}
+
 // The sampling pass on a descriptor whose scratch pointers (cum, partial) are set.
 static int az_sample_prioritized_impl(const az_replay* r, const az_replay_state* st,
                                       const uint32_t sample_key[2], float beta, int32_t bs,
@@ -300,16 +427,19 @@ static int az_sample_prioritized_impl(const az_replay* r, const az_replay_state*
   float* total = r->partial + 2 * nc;  // sum of the masked priorities
   unsigned int* wmax = reinterpret_cast<unsigned int*>(r->partial + 2 * nc + 1);
   // probs /= sum(probs): the sum is the last element of the (unnormalised) prefix sums
+  const bool in_kernel = nc <= AZ_CHUNKS_IN_KERNEL;
   if (int rc = az_scan_launch(r, st, nullptr, 0, 0.0f, nullptr, false, s)) return rc;
   k_scan_last<<<dim3(1), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, nullptr,
-                                                  r->partial + nc, total);
+                                                  r->partial + nc, in_kernel ? r->partial : nullptr, total, wmax);
   AZ_LAUNCH_CHECK();
-  AZ_HIP(hipMemsetAsync(wmax, 0, sizeof(unsigned int), s));
   if (int rc = az_scan_launch(r, st, total, 1, beta, wmax, true, s)) return rc;
-  k_weights_normalise<<<dim3(1024), dim3(256), 0, s>>>(*r, wmax);
-  AZ_LAUNCH_CHECK();
-  k_draw_prioritized<<<dim3((bs + 255) / 256), dim3(256), 0, s>>>(*r, sample_key[0], sample_key[1],
-                                                                   bs, out_idx);
+  // (the draw stays a binary search per thread: the prefix sums are not monotone to the last bit
+  // across run boundaries -- heavy-tailed priorities give a few inversions of one unit in the last
+  // place per 10^4 rows -- so only the same probe sequence finds the same index as the checker's
+  // searchsorted; a 64-way search was four round trips instead of twenty but not identical)
+  const int draw_blocks = (bs + 255) / 256;
+  k_draw_and_normalise<<<dim3(draw_blocks + 1024), dim3(256), 0, s>>>(*r, sample_key[0], sample_key[1], bs,
+                                                                      out_idx, draw_blocks, wmax);
   AZ_LAUNCH_CHECK();
   k_replay_gather<<<dim3(bs), dim3(64), 0, s>>>(*r, st->head, out_idx, out_batch);
   AZ_LAUNCH_CHECK();
@@ -479,7 +609,8 @@ extern "C" int az_replay_scan(const az_replay* r, const az_replay_state* st, flo
   const int nc = az_scan_chunks(r->cap);
   if (int rc = az_scan_launch(r, st, nullptr, 0, 0.0f, nullptr, true, s)) return rc;
   k_scan_last<<<dim3(1), dim3(AZ_SCAN_B), 0, s>>>(*r, st->insert_position, st->head, nullptr,
-                                                  r->partial + nc, out_total);
+                                                  r->partial + nc, nc <= AZ_CHUNKS_IN_KERNEL ? r->partial : nullptr,
+                                                  out_total, nullptr);
   AZ_LAUNCH_CHECK();
   k_copy_f32<<<dim3(256), dim3(256), 0, s>>>(r->cum, out_cum, r->cap);
   AZ_LAUNCH_CHECK();
