@@ -9,6 +9,17 @@
 #include <string>
 #include <vector>
 
+#ifdef AZ_STAMP
+// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation
+// (columns 0-9: the simulation loop's own stamps; 9 + k: stamp k of the path update).
+__device__ long long az_sim_stamps[64][16];
+#define AZ_WAVE_STAMP(k)                                                            \
+  do {                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sim < 64)                            \
+      az_sim_stamps[sim][9 + (k)] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
+#endif
+
 #include "az_host.h"
 #include "az_wave.h"
 #include "az_envs.h"
@@ -388,8 +399,6 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
 
 
 #ifdef AZ_STAMP
-// Diagnostic build only: cycle stamps of thread 0 of workgroup 0, one row per simulation.
-__device__ long long az_sim_stamps[64][16];
 #define AZ_SIM_STAMP(k)                                                                        \
   do {                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                           \

@@ -36,8 +36,11 @@ static int az_dispatch_ak(int A, int K, F&& f) {
 #ifndef AZ_NARROW_A
 #define AZ_NARROW_A 2
 #endif
-  if (A <= AZ_NARROW_A && K == 1) return f.template operator()<AZ_NARROW_A, 1>();
-  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A <= AZ_NARROW_A and K == 1 only");
+#ifndef AZ_NARROW_K
+#define AZ_NARROW_K 1
+#endif
+  if (A <= AZ_NARROW_A && K <= AZ_NARROW_K) return f.template operator()<AZ_NARROW_A, AZ_NARROW_K>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A <= AZ_NARROW_A and K <= AZ_NARROW_K only");
 #else
 #define AZ_K_CASES(AM)                                  \
   if (K == 1) return f.template operator()<AM, 1>();    \
@@ -59,8 +62,8 @@ static int az_dispatch_ak(int A, int K, F&& f) {
 template <typename F>
 static int az_dispatch_coop(int A, int K, F&& f) {
 #ifdef AZ_NARROW_BUILD
-  if (A == AZ_NARROW_A && K == 1) return f.template operator()<AZ_NARROW_A, 1, true>();
-  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A == AZ_NARROW_A and K == 1 only");
+  if (A == AZ_NARROW_A && K == AZ_NARROW_K) return f.template operator()<AZ_NARROW_A, AZ_NARROW_K, true>();
+  return az_fail(AZ_ERR_UNSUPPORTED, "narrow diagnostic build: A == AZ_NARROW_A and K == AZ_NARROW_K only");
 #else
   if (K == 1) {
     if (A == 2) return f.template operator()<2, 1, true>();

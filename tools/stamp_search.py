@@ -10,6 +10,10 @@ dev = torch.device("cuda")
 B, S = int(os.environ.get("B", 4096)), int(os.environ.get("S", 64))
 ENV = os.environ.get("ENV", "CartPole-v1")
 pol, val = make_networks(ENV, 1, dev)
+K = int(os.environ.get("K", 1))
+if K > 1:  # a K-atom value head on the same trunk
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    val = mctx.init_mlp((mctx.envs.observation_size(ENV), 256, 256, 256, 256, 256, K), generator=g, device=dev)
 model = mctx.FusedModel(ENV, pol, val, hidden_bf16=bool(int(os.environ.get("BF16", "0"))))
 env = mctx.envs.make(ENV)
 st = env.reset(0, batch_size=B)
@@ -42,3 +46,8 @@ for sim in range(min(S, 64)):
     tot_sum += np.array([int(nxt - row[0])] + d)
     print(f"{sim:3d} {int(nxt - row[0]):7d} | " + " ".join(f"{x:8d}" for x in d))
 print("mean", " ".join(f"{x:8.0f}" for x in tot_sum / min(S, 64)))
+# inside the update: stamps 3..6 of the path update (pass 0 of the last pass loop) and its end
+n = min(S, 64)
+cols = [4, 12, 13, 14, 15, 5]
+seg = np.array([[buf[i][cols[k + 1]] - buf[i][cols[k]] for k in range(5)] for i in range(n)], dtype=np.float64)
+print("update: load %.0f  chain %.0f  newval %.0f  store %.0f  select+entry %.0f" % tuple(seg.mean(0)))
