@@ -89,7 +89,12 @@ def mlp_apply(layers, x):
 
 
 def forward_networks(policy_layers, value_layers, mean, std, obs):
-    """alphazero.py:208-216 (differentiable twin of FusedModel.forward)."""
+    """alphazero.py:208-216 (differentiable twin of FusedModel.forward).  With value_layers None,
+    `policy_layers` is a networks object with forward(obs, mean, std) and leaves() of its own
+    (the shared convolutional torso with its two heads, alphazero.py:246-267): the normaliser is
+    applied once, in front of the torso (networks/networks.py:145-147)."""
+    if value_layers is None:
+        return policy_layers.forward(obs, mean, std)
     x = (obs - mean) / std
     return mlp_apply(policy_layers, x), mlp_apply(value_layers, x)
 
@@ -159,7 +164,7 @@ def compute_muzero_loss(policy_layers, value_layers, mean, std, data, num_atoms,
             norms = torch.stack(torch._foreach_norm(flat_leaves(policy_layers, value_layers)))
             l2 = l2_coef * 0.5 * (norms * norms).sum()
     else:
-        l2 = l2_coef * 0.5 * sum((w ** 2).sum() + (b ** 2).sum() for w, b in list(policy_layers) + list(value_layers))
+        l2 = l2_coef * 0.5 * sum((p ** 2).sum() for p in flat_leaves(policy_layers, value_layers))
     total = policy_loss + v_loss + l2
     with torch.no_grad():
         a = data["raw_action"].long()
@@ -238,6 +243,8 @@ class ClipAdam:
 
 
 def flat_leaves(policy_layers, value_layers):
+    if value_layers is None:    # a networks object (see forward_networks)
+        return list(policy_layers.leaves())
     return [t for w, b in list(policy_layers) + list(value_layers) for t in (w, b)]
 
 

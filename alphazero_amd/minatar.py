@@ -167,20 +167,34 @@ class AtariNetworks:
         self.policy = networks.init_mlp((f, num_actions), generator, device)
         self.value = networks.init_mlp((f, num_atoms), generator, device)
 
-    def forward(self, obs):
-        """alphazero.py:208-216 with use_feature_extractor: (prior logits [B,A], value [B,K])."""
+    def leaves(self):
+        """Every parameter tensor (the L2 penalty and the optimiser cover the torso too,
+        alphazero.py:787-789)."""
+        return self.torso.leaves() + [t for w, b in self.policy + self.value for t in (w, b)]
+
+    def forward(self, obs, mean=None, std=None):
+        """alphazero.py:208-216 with use_feature_extractor: (prior logits [B,A], value [B,K]).
+        obs [..., 10, 10, 4] or flattened [..., 400]; mean / std (flat or observation-shaped): the
+        running-statistics normaliser in front of the torso (networks/networks.py:145-147)."""
+        if obs.shape[-1] == OBS:
+            obs = obs.reshape(tuple(obs.shape[:-1]) + OBS_SHAPE)
+        if mean is not None:
+            obs = (obs - mean.reshape(OBS_SHAPE)) / std.reshape(OBS_SHAPE)
         h = self.torso(obs)
         (wp, bp), (wv, bv) = self.policy[0], self.value[0]
         return h @ wp + bp, h @ wv + bv
 
 
-def recurrent_fn(env, nets, gamma=0.99):
+def recurrent_fn(env, nets, gamma=0.99, normalizer=None):
     """alphazero.py:317-339 for this environment: step the model, evaluate the networks on the
-    new observation, discount = gamma * (1 if truncated else 1 - done)."""
+    new observation, discount = gamma * (1 if truncated else 1 - done).
+    normalizer (optional): a callable returning the current (mean, std) of the observation
+    statistics, read at every call."""
     def fn(params, rng_key, action, embedding):
         state, obs, reward, done, trunc = env.model_step(embedding["state"], action)
+        mean, std = normalizer() if normalizer is not None else (None, None)
         with torch.no_grad():
-            logits, value = nets.forward(obs)
+            logits, value = nets.forward(obs, mean, std)
         discount = gamma * torch.where(trunc != 0, torch.ones_like(done), 1 - done)
         return base.RecurrentFnOutput(reward=reward, discount=discount, prior_logits=logits,
                                       value=value), {"state": state}

@@ -4,7 +4,10 @@ Mirrors alphazero.py: `actor_step` (:287-403), `generate_unroll` (:406-430), `tr
 (:1092-1183), `prefill_replay_buffer` (:1224-1296) and the evaluator's episode loop
 (:433-508) for the built-in environments.  Self-play (search, environment, networks in
 the tree) runs in the HIP kernels; the learner side is `learner.py`; replay is
-`replay_buffers.py`.  Data parallelism follows alphazero.py:893-896, 935-943: every rank
+`replay_buffers.py`.  'Breakout-MinAtar' (is_atari_env, alphazero.py:878) takes the reference's
+other branch: the shared convolutional torso (alphazero.py:246-267, 1304-1308) evaluated by
+library calls, the search on the per-simulation kernels with the environment's HIP step as the
+model, flattened [400] observations in the replay rows.  Data parallelism follows alphazero.py:893-896, 935-943: every rank
 owns `num_envs // world` lanes, its share of the replay rows and of the sampled batch;
 the only collectives are the gradient mean per minibatch and the observation-statistics
 sums per training step (torch.distributed: RCCL on GPUs).
@@ -39,6 +42,7 @@ class Config:
     max_num_considered_actions: int = 16
     policy_hidden: tuple = (32, 32, 32, 32)
     value_hidden: tuple = (256, 256, 256, 256, 256)
+    atari_dense_layer_sizes: tuple = (256,)     # alphazero.py:100 (Breakout-MinAtar only)
     num_atoms: int = 1
     qr_kappa: float = 1.0
     use_gae: bool = True
@@ -84,17 +88,30 @@ class Trainer:
         self.lanes = shard.lanes
         self.key = shard.key
         self.env = envs_lib.make(cfg.env_id, episode_length=cfg.episode_length)
-        obs, act = envs_lib.observation_size(cfg.env_id), envs_lib.action_size(cfg.env_id)
+        self.atari = cfg.env_id == "Breakout-MinAtar"
         # identical initial parameters on every rank (alphazero.py:1305-1326 replicates them)
         g = torch.Generator(device=self.device).manual_seed(cfg.seed)
-        self.policy_layers = networks.init_mlp((obs,) + tuple(cfg.policy_hidden) + (act,), g, self.device)
-        self.value_layers = networks.init_mlp((obs,) + tuple(cfg.value_hidden) + (cfg.num_atoms,), g,
-                                              self.device)
-        self.stats = L.RunningStatistics(obs, device=self.device)
-        self.model = networks.FusedModel(cfg.env_id, self.policy_layers, self.value_layers,
-                                         self.stats.mean, self.stats.std, gamma=cfg.n_step_gamma,
-                                         hidden_bf16=cfg.selfplay_hidden_bf16)
-        self.recurrent_fn = networks.FusedRecurrentFn(self.model)
+        if self.atari:
+            from . import minatar
+            obs, act = minatar.OBS, minatar.ACTIONS
+            self.stats = L.RunningStatistics(obs, device=self.device)
+            # the learner's functions take the networks object in the policy slot (learner.forward_networks)
+            self.policy_layers = minatar.AtariNetworks(act, cfg.num_atoms, tuple(cfg.atari_dense_layer_sizes),
+                                                       generator=g, device=self.device)
+            self.value_layers = None
+            self.model = None
+            self.recurrent_fn = minatar.recurrent_fn(self.env, self.policy_layers, cfg.n_step_gamma,
+                                                     normalizer=self._normalizer)
+        else:
+            obs, act = envs_lib.observation_size(cfg.env_id), envs_lib.action_size(cfg.env_id)
+            self.policy_layers = networks.init_mlp((obs,) + tuple(cfg.policy_hidden) + (act,), g, self.device)
+            self.value_layers = networks.init_mlp((obs,) + tuple(cfg.value_hidden) + (cfg.num_atoms,), g,
+                                                  self.device)
+            self.stats = L.RunningStatistics(obs, device=self.device)
+            self.model = networks.FusedModel(cfg.env_id, self.policy_layers, self.value_layers,
+                                             self.stats.mean, self.stats.std, gamma=cfg.n_step_gamma,
+                                             hidden_bf16=cfg.selfplay_hidden_bf16)
+            self.recurrent_fn = networks.FusedRecurrentFn(self.model)
         self.optimizer = L.ClipAdam(L.flat_leaves(self.policy_layers, self.value_layers),
                                     cfg.learning_rate, cfg.max_grad_norm, cfg.anneal_lr,
                                     cfg.total_timesteps)
@@ -115,16 +132,28 @@ class Trainer:
         self._graphed = None
 
     # -------------------------------------------------------------- self-play
+    def _normalizer(self):
+        if self.cfg.normalize_observations:
+            return self.stats.mean, self.stats.std
+        return None, None
+
     def _refresh_model(self):
-        mean, std = (self.stats.mean, self.stats.std) if self.cfg.normalize_observations else (None, None)
-        self.model.update(self.policy_layers, self.value_layers, mean, std)
+        if self.model is not None:   # (the torso's networks are read in place)
+            self.model.update(self.policy_layers, self.value_layers, *self._normalizer())
+
+    def _forward(self, obs):
+        """alphazero.py:208-216 without gradients: (prior logits, value) of the current networks."""
+        if self.model is not None:
+            return self.model.forward(obs)
+        with torch.no_grad():
+            return self.policy_layers.forward(obs, *self._normalizer())
 
     def actor_step(self, key, deterministic=False, state=None):
         """alphazero.py:287-403: search on the states `state` (default: the training
         environments' current ones), act, step the environment."""
         cfg, st = self.cfg, self.env_state if state is None else state
         _, _, key = prng.split(key, 3)   # key, logits_rng, search_rng (:298); the search takes the third
-        logits, value = self.model.forward(st.obs)
+        logits, value = self._forward(st.obs)
         root = RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
         if cfg.policy == "gumbel":
             out = policies.gumbel_muzero_policy(
@@ -139,17 +168,20 @@ class Trainer:
                                                  cfg.num_simulations, num_samples=cfg.num_samples)
         action, search_value, log_prob = policies.actor_post(
             out.search_tree, out.action_weights, out.action, logits, deterministic=deterministic)
-        obs, real_obs = st.obs.clone(), st.real_obs.clone()
+        def rows_of(x):   # the replay rows hold flattened observations (a no-op for vectors)
+            return x.reshape(x.shape[0], -1)
+
+        obs, real_obs = rows_of(st.obs).clone(), rows_of(st.real_obs).clone()
         nst = self.env.step(st, action)
         if self.trace is not None:
             self.trace.append(dict(obs=obs, real_obs=real_obs, value=value, action=action,
                                    action_weights=out.action_weights, search_value=search_value,
                                    prior_log_prob=log_prob, reward=nst.reward, done=nst.done,
-                                   truncation=nst.truncation, next_real_obs=nst.real_obs,
+                                   truncation=nst.truncation, next_real_obs=rows_of(nst.real_obs),
                                    steps=nst.steps))
         ones = torch.ones_like(nst.reward)
         tr = dict(observation=obs, real_obs=real_obs, action=action.float(), reward=nst.reward,
-                  discount=1 - nst.done, next_observation=nst.real_obs,
+                  discount=1 - nst.done, next_observation=rows_of(nst.real_obs),
                   target_policy_probs=out.action_weights, search_value=search_value,
                   value_prefix_target=torch.zeros_like(nst.reward),
                   bootstrap_observation=torch.zeros_like(obs),
@@ -218,7 +250,9 @@ class Trainer:
         metrics = []
         loss_kw = dict(qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost, l2_coef=cfg.l2_coef,
                        per_importance_sampling=cfg.per_importance_sampling)
-        if cfg.graph_sgd and self.world == 1 and self.device.type == "cuda" and self._graphed is None:
+        # (the torso's convolutions stay outside graph capture: eager minibatches for Breakout)
+        if cfg.graph_sgd and self.world == 1 and self.device.type == "cuda" and self._graphed is None \
+                and not self.atari:
             self._graphed = L.GraphedMinibatchStep(
                 self.policy_layers, self.value_layers, self.optimizer, self.layout,
                 rows.shape[0] // cfg.num_minibatches, cfg.num_atoms, self.device, **loss_kw)
@@ -233,7 +267,7 @@ class Trainer:
         # refresh the priorities of the sampled rows with the PRE-update networks (:1177-1180)
         targets = batch["value_prefix_target"].unsqueeze(-1) + \
             batch["bootstrap_discount"].unsqueeze(-1) * batch["bootstrap_value"]
-        _, values = self.model.forward(batch["observation"].contiguous())
+        _, values = self._forward(batch["observation"].contiguous())
         self.replay.set_priorities(self.buffer_state, L.priorities(targets, values, cfg.per_alpha))
         self._refresh_model()
         out = {k: torch.stack([m[k] for m in metrics]).mean() for k in metrics[0]}

@@ -2,6 +2,8 @@
 restatement of gymnax's MinBreakout under the reference's wrappers, the convolutional torso
 against a NumPy evaluation, and a Gumbel search around both on the per-simulation kernels against
 the C checker fed with the recorded evaluations."""
+import math
+
 import numpy as np
 import pytest
 
@@ -189,3 +191,65 @@ def test_gumbel_search_around_breakout_and_the_torso(oracle=None):
                 continue
             _, s, _, _, _ = bk.step_env(bk.EnvState.from_words(emb[b, par[b, n]]), afp[b, n])
             assert np.array_equal(emb[b, n], s.words()), (b, n)
+
+
+@pytest.mark.parametrize("policy,atoms,per_alpha,normalize", [("gumbel", 1, 0.0, True), ("sampled", 4, 0.6, False)])
+def test_trainer_on_breakout_with_the_convolutional_torso(policy, atoms, per_alpha, normalize):
+    """alphazero.py with env_id 'Breakout-MinAtar' (is_atari_env, :878): training steps run end to
+    end -- search on the per-simulation kernels with the HIP model step and the torso networks,
+    flattened observations in the replay rows, L2 and the optimiser over the torso's parameters
+    too (:787-789, :1304-1308).  The loss the learner minimises is checked against a direct
+    restatement with torch's functional convolutions on the same minibatch.
+    (normalize_observations off in one case: a cell that never lit up during the first unrolls
+    has the minimum deviation of 1e-6, running_statistics.py:75-180, and the first time it does the
+    networks see 1e6 -- the reference's arithmetic, but the metrics are no longer finite.)"""
+    import torch
+    import torch.nn.functional as F
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from alphazero_amd import learner as L, minatar
+    from alphazero_amd.trainer import Config, Trainer
+    cfg = Config(env_id="Breakout-MinAtar", num_envs=32, unroll_length=5, num_simulations=8, policy=policy,
+                 num_atoms=atoms, per_alpha=per_alpha, max_replay_size=1024, min_replay_size=0,
+                 replay_buffer_batch_size=16, num_minibatches=4, num_samples=6, episode_length=50,
+                 atari_dense_layer_sizes=(64,), use_gae=(atoms == 1), normalize_observations=normalize)
+    tr = Trainer(cfg, device="cuda")
+    nets = tr.policy_layers
+    assert isinstance(nets, minatar.AtariNetworks) and tr.value_layers is None
+    assert len(tr.optimizer.params) == len(nets.leaves()) == 2 * (2 + 2 + 1 + 1)
+    assert tr.layout["observation"][1] == 400 and tr.layout["_width"] == 4 * 400 + 3 + 2 * atoms + 10
+    before = [p.clone() for p in tr.optimizer.params]
+    tr.trace = []
+    m = tr.train(2)
+    assert all(math.isfinite(v) for v in m.values()), m
+    assert m["buffer_current_size"] == 2 * 5 * 32 and tr.optimizer.count == 2 * cfg.num_minibatches
+    assert tr.stats.count == (2 * 5 * 32 if normalize else 0) and tr.stats.mean.shape == (400,)
+    changed = [not torch.equal(a, b) for a, b in zip(before, tr.optimizer.params)]
+    assert all(changed[i] for i in (0, 2, 4)), changed          # both convolutions and the first dense layer moved
+    # the replay rows hold the flattened observation the search saw, and 0/1 cells only
+    step0 = tr.trace[0]
+    assert step0["obs"].shape == (32, 400) and set(step0["obs"].unique().tolist()) <= {0.0, 1.0}
+    assert step0["action_weights"].shape == (32, 3)
+    torch.testing.assert_close(step0["action_weights"].sum(-1), torch.ones(32, device="cuda"))
+    # the loss on one minibatch against a direct restatement
+    _, rows = tr.replay.sample(tr.buffer_state)
+    data = L.unpack_rows(tr.layout, rows[:16])
+    mean, std = tr.stats.mean, tr.stats.std
+    total, met = L.compute_muzero_loss(nets, None, mean, std, data, atoms, l2_coef=cfg.l2_coef,
+                                       vf_cost=cfg.vf_cost, qr_kappa=cfg.qr_kappa)
+    x = ((data["observation"] - mean) / std).reshape(-1, 10, 10, 4).permute(0, 3, 1, 2)
+    for w, b in nets.torso.conv:
+        x = F.relu(F.conv2d(x, w.permute(3, 2, 0, 1), b))
+    x = x.permute(0, 2, 3, 1).reshape(16, -1)
+    x = x @ nets.torso.dense[0][0] + nets.torso.dense[0][1]
+    x = F.relu(x @ nets.torso.dense[1][0] + nets.torso.dense[1][1])
+    logits = x @ nets.policy[0][0] + nets.policy[0][1]
+    value = x @ nets.value[0][0] + nets.value[0][1]
+    vs = data["value_prefix_target"][:, None] + data["bootstrap_discount"][:, None] * data["bootstrap_value"]
+    vl = L.quantile_regression_loss(value, vs, cfg.qr_kappa, atoms) if atoms > 1 else L.mse_value_loss(value, vs)
+    want = -(data["target_policy_probs"] * F.log_softmax(logits, -1)).sum(-1).mean() \
+        + cfg.vf_cost * (vl * data["weight"]).mean() \
+        + cfg.l2_coef * 0.5 * sum((p.double() ** 2).sum() for p in nets.leaves()).float()
+    torch.testing.assert_close(total, want, rtol=1e-5, atol=1e-6)
+    ev = tr.evaluate(num_eval_envs=8, episode_length=20)
+    assert ev["eval/avg_episode_length"] > 0 and math.isfinite(ev["eval/episode_reward"])

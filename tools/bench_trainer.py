@@ -30,6 +30,10 @@ CASES = {
     # sampled search with a quantile-regression value head
     "cartpole_sampled_qr": dict(env_id="CartPole-v1", policy="sampled", num_envs=4096, num_simulations=64,
                                 num_samples=16, num_atoms=8),
+    # MinAtar Breakout with the convolutional torso: the search runs on the per-simulation kernels,
+    # the networks through library convolutions (rows of 1616 floats: a smaller replay)
+    "breakout_torso": dict(env_id="Breakout-MinAtar", policy="gumbel", num_envs=2048, num_simulations=32,
+                           normalize_observations=False, max_replay_size=1 << 17),
 }
 
 
@@ -57,8 +61,8 @@ def main():
             continue
         kw = dict(kw)
         kw["num_envs"] *= world          # weak scaling: the same lanes per GPU
-        cfg = Config(unroll_length=8, replay_buffer_batch_size=1024, num_minibatches=4,
-                     max_replay_size=(1 << 20) * world, **kw)
+        kw["max_replay_size"] = kw.get("max_replay_size", 1 << 20) * world
+        cfg = Config(unroll_length=8, replay_buffer_batch_size=1024, num_minibatches=4, **kw)
         tr = Trainer(cfg)
         for _ in range(args.warmup):
             tr.training_step()
