@@ -17,7 +17,7 @@ MAX_WIDTH = 1024
 
 VARIANT_MUZERO, VARIANT_SAMPLED, VARIANT_GUMBEL = 0, 1, 2
 QT_PARENT_SIBLINGS, QT_COMPLETED_MIX, QT_MIN_MAX = 0, 1, 2
-ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_ACROBOT = 1, 2, 3
+ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_ACROBOT, ENV_ACROBOT_NOTERM = 1, 2, 3, 4
 NOISE_THREEFRY, NOISE_INJECTED, NOISE_ZERO = 0, 1, 2
 VARIANT_STOCHASTIC = 3
 

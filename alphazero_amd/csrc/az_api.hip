@@ -499,7 +499,7 @@ __global__ void k_env_reset(int env_id, int B, const uint32_t* __restrict__ keys
 
 extern "C" int az_env_reset(int32_t env_id, int32_t B, const uint32_t* keys, float* state,
                             int32_t* time, float* obs, uint32_t* rng_out, void* stream) {
-  if (env_id < AZ_ENV_CARTPOLE || env_id > AZ_ENV_ACROBOT)
+  if (env_id < AZ_ENV_CARTPOLE || env_id > AZ_ENV_ACROBOT_NOTERM)
     return az_fail(AZ_ERR_UNSUPPORTED, "unknown env_id %d", env_id);
   if (B < 1 || !keys || !state || !time || !obs) return az_fail(AZ_ERR_INVALID, "bad reset arguments");
   k_env_reset<<<dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(env_id, B, keys, state,
@@ -549,7 +549,7 @@ extern "C" int az_real_env_step(int32_t env_id, int32_t B, int32_t episode_lengt
                                 int32_t* time, float* obs, float* real_obs, float* reward,
                                 float* done, float* truncation, float* steps, uint32_t* rng,
                                 const int32_t* action, void* stream) {
-  if (env_id < AZ_ENV_CARTPOLE || env_id > AZ_ENV_ACROBOT)
+  if (env_id < AZ_ENV_CARTPOLE || env_id > AZ_ENV_ACROBOT_NOTERM)
     return az_fail(AZ_ERR_UNSUPPORTED, "unknown env_id %d", env_id);
   if (B < 1 || !state || !time || !obs || !real_obs || !reward || !done || !truncation || !steps ||
       !rng || !action)

@@ -232,6 +232,7 @@ AZ_DEV void az_env_step_rt(int env_id, EnvState& st, int action, EnvOut& o) {
     az_env_out_copy(o, t);
   } else {
     az_acrobot_step(st, action, t);
+    if (env_id == AZ_ENV_ACROBOT_NOTERM) t.terminated = 0.0f;  // acrobot_no_term.py:151-157
     az_env_out_copy(o, t);
   }
 }
@@ -250,6 +251,7 @@ AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut
       az_env_out_copy(o, t);
     } else {
       az_acrobot_step<QUAD>(st, action, t);
+      if (env_id == AZ_ENV_ACROBOT_NOTERM) t.terminated = 0.0f;  // acrobot_no_term.py:151-157
       az_env_out_copy(o, t);
     }
   } else {
@@ -263,7 +265,7 @@ AZ_DEV void az_env_step_for_actions(int env_id, EnvState& st, int action, EnvOut
 // compiler has been seen to leave undefined on one of the paths.
 AZ_DEV void az_env_obs(int env_id, const EnvState& st, float* obs) {
   float o[6] = {st.s[0], st.s[1], st.s[2], st.s[3], 0.0f, 0.0f};  // CartPole: the state; MountainCar: its first two
-  if (env_id == AZ_ENV_ACROBOT) {
+  if (env_id >= AZ_ENV_ACROBOT) {  // (both Acrobot variants)
     const float c1 = az_cosf(st.s[0]), s1 = az_sinf(st.s[0]);
     const float c2 = az_cosf(st.s[1]), s2 = az_sinf(st.s[1]);
     o[0] = c1;

@@ -139,7 +139,7 @@ extern "C" int az_model_pack_bf16(const az_mlp_params* policy, const az_mlp_para
 
 static int az_model_dev(const az_model* m, ModelDev* md) {
   if (!m) return az_fail(AZ_ERR_INVALID, "null model");
-  if (m->env_id < AZ_ENV_CARTPOLE || m->env_id > AZ_ENV_ACROBOT)
+  if (m->env_id < AZ_ENV_CARTPOLE || m->env_id > AZ_ENV_ACROBOT_NOTERM)
     return az_fail(AZ_ERR_UNSUPPORTED, "unknown env_id %d", m->env_id);
   if (!m->packed || !m->norm_mean || !m->norm_std)
     return az_fail(AZ_ERR_INVALID, "model has null buffers");

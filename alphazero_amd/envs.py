@@ -1,4 +1,5 @@
-"""The built-in environments (CartPole-v1, MountainCar-v0, Acrobot-v1).
+"""The built-in environments (CartPole-v1, MountainCar-v0, Acrobot-v1 and its
+never-terminating variant Acrobot-v2, gymnax registration.py:28-37).
 
 Mirrors the training environment the reference builds at alphazero.py:884-890:
 ``AutoResetWrapper(VmapWrapper(EpisodeWrapper(GymnaxToBraxWrapper(env))))`` for the
@@ -18,9 +19,10 @@ from . import _native as nat
 from . import prng
 
 ENV_IDS = {"CartPole-v1": nat.ENV_CARTPOLE, "MountainCar-v0": nat.ENV_MOUNTAINCAR,
-           "Acrobot-v1": nat.ENV_ACROBOT}
-_OBS = {nat.ENV_CARTPOLE: 4, nat.ENV_MOUNTAINCAR: 2, nat.ENV_ACROBOT: 6}
-_ACT = {nat.ENV_CARTPOLE: 2, nat.ENV_MOUNTAINCAR: 3, nat.ENV_ACROBOT: 3}
+           "Acrobot-v1": nat.ENV_ACROBOT,
+           "Acrobot-v2": nat.ENV_ACROBOT_NOTERM}   # AcrobotNoTerm (gymnax registration.py:36-37)
+_OBS = {nat.ENV_CARTPOLE: 4, nat.ENV_MOUNTAINCAR: 2, nat.ENV_ACROBOT: 6, nat.ENV_ACROBOT_NOTERM: 6}
+_ACT = {nat.ENV_CARTPOLE: 2, nat.ENV_MOUNTAINCAR: 3, nat.ENV_ACROBOT: 3, nat.ENV_ACROBOT_NOTERM: 3}
 
 
 def env_code(env_id):

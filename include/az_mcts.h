@@ -29,7 +29,10 @@ extern "C" {
 enum { AZ_OK = 0, AZ_ERR_INVALID = -1, AZ_ERR_UNSUPPORTED = -2, AZ_ERR_HIP = -3 };
 enum { AZ_VARIANT_MUZERO = 0, AZ_VARIANT_SAMPLED = 1, AZ_VARIANT_GUMBEL = 2, AZ_VARIANT_STOCHASTIC = 3 };
 enum { AZ_QT_PARENT_SIBLINGS = 0, AZ_QT_COMPLETED_MIX = 1, AZ_QT_MIN_MAX = 2 };
-enum { AZ_ENV_CARTPOLE = 1, AZ_ENV_MOUNTAINCAR = 2, AZ_ENV_ACROBOT = 3 };
+/* AZ_ENV_ACROBOT_NOTERM: 'Acrobot-v2' (gymnax registration.py:36-37, acrobot_no_term.py): the
+ * dynamics, reward and observation of Acrobot-v1 with `done` always 0 (is_terminal, :151-157);
+ * episodes end by truncation only. */
+enum { AZ_ENV_CARTPOLE = 1, AZ_ENV_MOUNTAINCAR = 2, AZ_ENV_ACROBOT = 3, AZ_ENV_ACROBOT_NOTERM = 4 };
 enum { AZ_NOISE_THREEFRY = 0, AZ_NOISE_INJECTED = 1, AZ_NOISE_ZERO = 2 };
 
 /* Static description of one search() call (mctx_dist/_src/search.py:31-43 plus

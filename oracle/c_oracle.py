@@ -16,7 +16,7 @@ _LIB = None
 MAX_LAYERS = 8
 VARIANTS = {"muzero": 0, "sampled": 1, "gumbel": 2, "stochastic": 3}
 QTRANSFORMS = {"parent_and_siblings": 0, "completed_by_mix_value": 1, "min_max": 2}
-ENVS = {"none": 0, "CartPole-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3}
+ENVS = {"none": 0, "CartPole-v1": 1, "MountainCar-v0": 2, "Acrobot-v1": 3, "Acrobot-v2": 4}
 NOISE = {"threefry": 0, "injected": 1, "zero": 2}
 
 

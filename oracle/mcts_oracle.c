@@ -644,8 +644,10 @@ static void oz_env_step_one(int env_id, env_state_t* st, int action, env_out_t* 
     cartpole_step(st, action, o);
   else if (env_id == OZ_ENV_MOUNTAINCAR)
     mountaincar_step(st, action, o);
-  else
+  else {
     acrobot_step(st, action, o);
+    if (env_id == OZ_ENV_ACROBOT_NOTERM) o->terminated = 0.0f; /* acrobot_no_term.py:151-157 */
+  }
 }
 
 static void oz_env_obs(int env_id, const env_state_t* st, float* obs) {

@@ -23,7 +23,8 @@
 
 enum { OZ_VARIANT_MUZERO = 0, OZ_VARIANT_SAMPLED = 1, OZ_VARIANT_GUMBEL = 2, OZ_VARIANT_STOCHASTIC = 3 };
 enum { OZ_QT_PARENT_SIBLINGS = 0, OZ_QT_COMPLETED_MIX = 1, OZ_QT_MIN_MAX = 2 };
-enum { OZ_ENV_NONE = 0, OZ_ENV_CARTPOLE = 1, OZ_ENV_MOUNTAINCAR = 2, OZ_ENV_ACROBOT = 3 };
+enum { OZ_ENV_NONE = 0, OZ_ENV_CARTPOLE = 1, OZ_ENV_MOUNTAINCAR = 2, OZ_ENV_ACROBOT = 3,
+       OZ_ENV_ACROBOT_NOTERM = 4 /* acrobot_no_term.py: Acrobot with done = 0 */ };
 enum { OZ_NOISE_THREEFRY = 0, OZ_NOISE_INJECTED = 1, OZ_NOISE_ZERO = 2 };
 
 typedef struct {

@@ -444,8 +444,14 @@ def acrobot_step(s, time, action):
     return st, time + 1, obs, reward, f32(done_angle), f32(time + 1 >= 5000)
 
 
+def acrobot_no_term_step(s, time, action):
+    """acrobot_no_term.py:52-108, 151-157: Acrobot's step with done = 0."""
+    st, time, obs, reward, _, truncated = acrobot_step(s, time, action)
+    return st, time, obs, reward, f32(0.0), truncated
+
+
 ENV_STEP = {"CartPole-v1": cartpole_step, "MountainCar-v0": mountaincar_step,
-            "Acrobot-v1": acrobot_step}
+            "Acrobot-v1": acrobot_step, "Acrobot-v2": acrobot_no_term_step}
 
 
 # ---------------------------------------------------------------- networks

@@ -297,7 +297,7 @@ def lecun_uniform_mlp(rng, sizes):
     return layers
 
 
-ENV_DIMS = {"CartPole-v1": (4, 2), "MountainCar-v0": (2, 3), "Acrobot-v1": (6, 3)}
+ENV_DIMS = {"CartPole-v1": (4, 2), "MountainCar-v0": (2, 3), "Acrobot-v1": (6, 3), "Acrobot-v2": (6, 3)}
 
 
 def synthetic_case(variant, B, S, A=None, K=1, seed=0, *, env_id=None, max_depth=None,

@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 WIDTHS = [1, 5, 16, 17, 31, 32, 33, 48, 64, 100, 128, 200, 256, 257, 300, 512, 600, 1024]
 bad = rejected = 0
 for i in range(n_cases):
-    env_id = ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"][rng.integers(3)]
+    env_id = ["CartPole-v1", "MountainCar-v0", "Acrobot-v1", "Acrobot-v2"][rng.integers(4)]
     ph = tuple(int(rng.choice(WIDTHS)) for _ in range(rng.integers(0, 7)))
     vh = tuple(int(rng.choice(WIDTHS)) for _ in range(rng.integers(0, 7)))
     K = int(rng.choice([1, 3, 8, 20, 64]))

@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 WIDTHS = [1, 5, 16, 17, 32, 33, 48, 64, 100, 128, 200, 256, 300]
 bad = rejected = 0
 for i in range(n_cases):
-    env_id = ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"][rng.integers(3)]
+    env_id = ["CartPole-v1", "MountainCar-v0", "Acrobot-v1", "Acrobot-v2"][rng.integers(4)]
     variant = ["gumbel", "muzero", "sampled"][rng.integers(3)]
     ph = tuple(int(rng.choice(WIDTHS)) for _ in range(rng.integers(0, 5)))
     vh = tuple(int(rng.choice(WIDTHS)) for _ in range(rng.integers(0, 6)))

@@ -163,7 +163,7 @@ def test_golden_fixture(hip):
 
 
 # ---------------------------------------------------------------- model pieces
-@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"])
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1", "Acrobot-v2"])
 def test_forward_and_recurrent_step_vs_oracle(hip, oracle, env_id):
     import alphazero_amd as mctx
     rng = np.random.default_rng(5)
@@ -239,6 +239,8 @@ FUSED_CASES = [
     ("MountainCar-v0", "muzero", 16, 12, 1, {}),
     ("Acrobot-v1", "gumbel", 16, 12, 1, {}),
     ("Acrobot-v1", "sampled", 16, 12, 8, {}),
+    ("Acrobot-v2", "gumbel", 16, 24, 1, {}),        # AcrobotNoTerm: never terminated, truncation only
+    ("Acrobot-v2", "muzero", 16, 12, 1, {}),
     ("CartPole-v1", "sampled", 20, 40, 16, {}),     # 16-atom value head
     ("MountainCar-v0", "gumbel", 16, 24, 16, {}),
     ("CartPole-v1", "gumbel", 16, 20, 1, dict(max_depth=3)),
@@ -511,7 +513,7 @@ def test_dirichlet_statistics(hip):
 
 
 # ---------------------------------------------------------------- environment + actor glue
-@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1"])
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "MountainCar-v0", "Acrobot-v1", "Acrobot-v2"])
 def test_real_env_step_vs_oracle(hip, oracle, env_id):
     import alphazero_amd as mctx
     env = mctx.envs.make(env_id, episode_length=7)

@@ -75,7 +75,7 @@ def test_c_vs_numpy_temperatures(variant, extra):
 
 @pytest.mark.parametrize("env_id,variant", [("CartPole-v1", "gumbel"), ("CartPole-v1", "muzero"),
                                             ("MountainCar-v0", "muzero"), ("Acrobot-v1", "gumbel"),
-                                            ("Acrobot-v1", "sampled")])
+                                            ("Acrobot-v1", "sampled"), ("Acrobot-v2", "gumbel")])
 def test_c_vs_numpy_model(env_id, variant):
     case = runners.synthetic_case(variant, B=8, S=12, K=1, seed=3, env_id=env_id,
                                   policy_hidden=(32, 32), value_hidden=(64, 64, 64),

@@ -200,6 +200,16 @@ def test_kat5_acrobot(oracle):
         sn, _, obs, r, term, trunc = mn.acrobot_step(s, 0, a)
         np.testing.assert_allclose(oc["state"][0], sn, rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(oc["obs"][0], obs, rtol=2e-5, atol=2e-5)
+    # Acrobot-v2 (acrobot_no_term.py:151-157): the same step, reward included, with done = 0
+    st = np.array([[3.0, 0.0, 0.0, 0.0]], np.float32)
+    o1 = oracle.env_step("Acrobot-v1", st, np.zeros(1), np.array([1]))
+    o2 = oracle.env_step("Acrobot-v2", st, np.zeros(1), np.array([1]))
+    assert o1["terminated"][0] == 1.0 and o2["terminated"][0] == 0.0    # (the upright case above)
+    assert o2["reward"][0] == o1["reward"][0] == 0.0                     # the reward keeps the angle test
+    assert np.array_equal(o1["state"], o2["state"]) and np.array_equal(o1["obs"], o2["obs"])
+    o2 = oracle.env_step("Acrobot-v2", st, np.array([4999]), np.array([1]))
+    assert o2["truncated"][0] == 1.0 and o2["terminated"][0] == 0.0
+    assert mn.acrobot_no_term_step(st[0], 0, 1)[4] == 0.0
 
 
 # ---- KAT-6: qtransforms on an all-unvisited node (qtransforms.py:54-149)
