@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alphazero_amd import _native as nat
-nat.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libaz_mcts_stamp.so")
+nat.LIB_PATH = os.environ.get("AZ_MCTS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libaz_mcts_stamp.so")
 import numpy as np, torch
 import alphazero_amd as mctx
 from bench import make_networks
