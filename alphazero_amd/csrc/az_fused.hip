@@ -54,7 +54,8 @@ static int64_t az_packed_floats(const az_mlp_params* policy, const az_mlp_params
   if (hidden_bf16 && (az_check_bf16(policy, "policy") || az_check_bf16(value, "value"))) return -1;
   MlpLayout lp, lv;
   int64_t off = az_mlp_layout(policy->n_layers, policy->sizes, 0, &lp, hidden_bf16);
-  return az_mlp_layout(value->n_layers, value->sizes, off, &lv, hidden_bf16);
+  // (behind the weights: the networks' schedule table, az_mlp_table_load)
+  return az_mlp_layout(value->n_layers, value->sizes, off, &lv, hidden_bf16) + AZ_TABLE_MAX_WORDS;
 }
 extern "C" int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params* value) {
   return az_packed_floats(policy, value, 0);
@@ -98,6 +99,59 @@ __global__ void k_pack_layer_bf16(const float* __restrict__ w, const float* __re
     bp[n] = n < nout ? bsrc[n] : 0.0f;
 }
 
+// The parts of a ModelDev that follow from the networks alone: layouts, widest layers, schedule
+// sizes, where the schedule table sits behind the weights and what its header must say.  AZ_OK, or
+// the reason why the kernels cannot run these networks.
+static int az_networks_dev(const az_mlp_params* pp, const az_mlp_params* vp, int hidden_bf16, const float* packed,
+                           ModelDev* md) {
+  md->bf16 = hidden_bf16 ? 1 : 0;
+  int64_t off = az_mlp_layout(pp->n_layers, pp->sizes, 0, &md->pol, md->bf16);
+  const int64_t weights_end = az_mlp_layout(vp->n_layers, vp->sizes, off, &md->val, md->bf16);
+  int pk = 16, vk = 16;
+  for (int i = 0; i < md->pol.n_layers; ++i) pk = md->pol.np[i] > pk ? md->pol.np[i] : pk;
+  for (int i = 0; i < md->val.n_layers; ++i) vk = md->val.np[i] > vk ? md->val.np[i] : vk;
+  md->pol_kp = pk;
+  md->val_kp = vk;
+  md->packed = packed;
+  md->table = reinterpret_cast<const uint32_t*>(packed + weights_end);
+  md->head_floats = 0;
+  md->head_floats = az_mlp_head_floats(*md);  // (before anything that depends on the unit phases)
+  md->tab_units = az_mlp_units_per_wave(*md) > 0 ? az_mlp_units_per_wave(*md) : 1;
+  if (az_mlp_units_per_wave(*md) > AZ_TABLE_UNITS)
+    return az_fail(AZ_ERR_UNSUPPORTED,
+                   "the networks need %d work units per wave, the schedule table holds %d "
+                   "(fewer or narrower layers, or a recurrent_fn in Python through the callback path)",
+                   az_mlp_units_per_wave(*md), AZ_TABLE_UNITS);
+  if ((size_t)az_mlp_lds_floats(pk, vk, md->tab_units, md->head_floats) * 4 > 160 * 1024)
+    return az_fail(AZ_ERR_UNSUPPORTED, "layer widths %d / %d need more than 160 KiB of LDS", pk, vk);
+  md->table_hash = az_mlp_table_hash(*md);
+  return AZ_OK;
+}
+
+// The schedule table of `md`, built by the kernels' own functions in LDS and copied out behind the
+// weights (layout: az_mlp.h, above az_mlp_table_load).  One workgroup.
+__global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_table_build(ModelDev md, uint32_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  MlpLds s(lds, md.pol_kp, md.val_kp, md.tab_units);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int words = AZ_MLP_WAVES * md.tab_units * AZ_UNIT_WORDS;
+  for (int i = tid; i < words; i += blockDim.x) s.tab[i] = 0u;  // (rows a wave does not use)
+  __syncthreads();
+  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  __syncthreads();
+  for (int i = tid; i < words; i += blockDim.x) out[AZ_TABLE_HDR_WORDS + i] = s.tab[i];
+  for (int i = tid; i < 16; i += blockDim.x) out[4 + i] = (uint32_t)s.tab_n[i];
+  if (tid == 0) {
+    const uint64_t base = (uint64_t)(uintptr_t)md.packed;
+    out[0] = md.table_hash;
+    out[1] = (uint32_t)md.tab_units;
+    out[2] = (uint32_t)base;
+    out[3] = (uint32_t)(base >> 32);
+  }
+}
+
+static int az_set_lds(const void* fn, size_t bytes);
+
 static int az_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed, int hidden_bf16,
                    void* stream) {
   if (int rc = az_check_mlp(policy, "policy")) return rc;
@@ -126,6 +180,20 @@ static int az_pack(const az_mlp_params* policy, const az_mlp_params* value, floa
             packed + L[net].w_off[i], packed + L[net].b_off[i]);
       AZ_LAUNCH_CHECK();
     }
+  // the schedule table behind the weights; networks the kernels cannot run (they say why when
+  // asked to) get a header that matches nothing
+  ModelDev md{};
+  uint32_t* table = nullptr;
+  if (az_networks_dev(policy, value, hidden_bf16, packed, &md) == AZ_OK) {
+    table = const_cast<uint32_t*>(md.table);
+    const size_t lds = (size_t)az_mlp_lds_floats(md.pol_kp, md.val_kp, md.tab_units, md.head_floats) * 4;
+    if (int rc = az_set_lds((const void*)k_table_build, lds)) return rc;
+    k_table_build<<<dim3(1), dim3(AZ_MLP_WAVES * 64), lds, (hipStream_t)stream>>>(md, table);
+    AZ_LAUNCH_CHECK();
+  } else {
+    table = const_cast<uint32_t*>(md.table);
+    AZ_HIP(hipMemsetAsync(table, 0, AZ_TABLE_HDR_WORDS * 4, (hipStream_t)stream));
+  }
   return AZ_OK;
 }
 extern "C" int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
@@ -164,32 +232,13 @@ static int az_model_dev(const az_model* m, ModelDev* md) {
   md->obs_dim = od;
   md->A = na;
   md->K = m->num_atoms;
-  md->bf16 = m->hidden_bf16 ? 1 : 0;
-  if (md->bf16) {
+  if (m->hidden_bf16) {
     if (int rc = az_check_bf16(&pp, "policy")) return rc;
     if (int rc = az_check_bf16(&vp, "value")) return rc;
   }
-  int64_t off = az_mlp_layout(pp.n_layers, pp.sizes, 0, &md->pol, md->bf16);
-  az_mlp_layout(vp.n_layers, vp.sizes, off, &md->val, md->bf16);
-  int pk = 16, vk = 16;
-  for (int i = 0; i < md->pol.n_layers; ++i) pk = md->pol.np[i] > pk ? md->pol.np[i] : pk;
-  for (int i = 0; i < md->val.n_layers; ++i) vk = md->val.np[i] > vk ? md->val.np[i] : vk;
-  md->pol_kp = pk;
-  md->val_kp = vk;
-  md->packed = m->packed;
   md->mean = m->norm_mean;
   md->std = m->norm_std;
-  md->head_floats = 0;
-  md->head_floats = az_mlp_head_floats(*md);  // (before anything that depends on the unit phases)
-  md->tab_units = az_mlp_units_per_wave(*md) > 0 ? az_mlp_units_per_wave(*md) : 1;
-  if (az_mlp_units_per_wave(*md) > AZ_TABLE_UNITS)
-    return az_fail(AZ_ERR_UNSUPPORTED,
-                   "the networks need %d work units per wave, the schedule table holds %d "
-                   "(fewer or narrower layers, or a recurrent_fn in Python through the callback path)",
-                   az_mlp_units_per_wave(*md), AZ_TABLE_UNITS);
-  if ((size_t)az_mlp_lds_floats(pk, vk, md->tab_units, md->head_floats) * 4 > 160 * 1024)
-    return az_fail(AZ_ERR_UNSUPPORTED, "layer widths %d / %d need more than 160 KiB of LDS", pk, vk);
-  return AZ_OK;
+  return az_networks_dev(&pp, &vp, m->hidden_bf16, m->packed, md);
 }
 
 // running_statistics.py:183-199 on one observation row, written in the permuted
@@ -232,6 +281,17 @@ AZ_DEV void az_stage_inputs(const ModelDev& md, const MlpLds& s, int tid, int nt
   az_mlp_stage_heads(md, s, tid, nthreads);
 }
 
+#ifdef AZ_STAMP
+// Diagnostic build only: kernel-entry stamps of workgroup 0 in the last columns of the forward stamps.
+#define AZ_FWD_EDGE(k)                                                                          \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && lane == 0) az_stamps[wave][k] = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+#else
+#define AZ_FWD_EDGE(k) \
+  do {                 \
+  } while (0)
+#endif
 template <bool BF16>
 __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int B,
                                                                const float* __restrict__ obs,
@@ -240,15 +300,19 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_forward(ModelDev md, int 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   MlpLds s(lds, md.pol_kp, md.val_kp, md.tab_units);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  AZ_FWD_EDGE(60);
   az_stage_inputs(md, s, tid, blockDim.x);
-  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  AZ_FWD_EDGE(61);
+  az_mlp_table_setup<AZ_MLP_WAVES>(md, s, tid, blockDim.x, wave, lane);
   __syncthreads();
+  AZ_FWD_EDGE(62);
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) az_store_obs<false>(md, s, tid, obs + (size_t)b * md.obs_dim);
   __syncthreads();
   MlpRegs regs;
   MlpFirst first;
   az_forward_prime<AZ_MLP_WAVES, BF16 ? AZ_SLOTS_BF16 : AZ_SLOTS>(md, s, wave, lane, regs, first, true);
+  AZ_FWD_EDGE(63);
   az_forward_tile<AZ_MLP_WAVES, false, BF16>(md, s, wave, lane, regs, first);
   if (tid < 16 && b < B) {
     for (int a = 0; a < md.A; ++a) logits[(size_t)b * md.A + a] = s.logits[tid * AZ_MAX_ACTIONS + a];
@@ -294,7 +358,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_recurrent_step(
   MlpLds s(lds, md.pol_kp, md.val_kp, md.tab_units);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   az_stage_inputs(md, s, tid, blockDim.x);
-  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  az_mlp_table_setup<AZ_MLP_WAVES>(md, s, tid, blockDim.x, wave, lane);
   __syncthreads();
   const int b = blockIdx.x * 16 + tid;
   if (tid < 16 && b < B) {
@@ -353,7 +417,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused(SearchCtx c,
   const bool active = tid < 16 && b < d.B;
   Lane<AMAX, KMAX> l(t, active ? b : 0, d.S + 1, d.A, d.K);
   az_stage_inputs(md, s, tid, blockDim.x);
-  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  az_mlp_table_setup<AZ_MLP_WAVES>(md, s, tid, blockDim.x, wave, lane);
   __syncthreads();
   MlpRegs regs;
   MlpFirst first;
@@ -467,7 +531,7 @@ __global__ __launch_bounds__(AZ_MLP_WAVES * 64) void k_search_fused_wave(
       emb[node * 5 + 4] = az_u2f((uint32_t)l.et[node]);
     }
   }
-  az_mlp_table_build<AZ_MLP_WAVES>(md, s, wave, lane);
+  az_mlp_table_setup<AZ_MLP_WAVES>(md, s, tid, blockDim.x, wave, lane);
   if (j == 0) ws.hdr[6] = 0;  // the lane's sum of path depths (in LDS: one register fewer across the networks)
   __syncthreads();
   for (int sim = 0; sim < S; ++sim) {

@@ -73,6 +73,8 @@ struct ModelDev {
   const float* packed;
   const float* mean;
   const float* std;
+  const uint32_t* table;  // the schedule table az_model_pack left behind the weights (az_mlp_table_load)
+  uint32_t table_hash;    // az_mlp_table_hash of this model: what that table's header must say
 };
 
 __host__ __device__ inline int az_ceil16(int x) { return (x + 15) & ~15; }
@@ -383,6 +385,71 @@ AZ_DEV void az_mlp_table_build(const ModelDev& md, const MlpLds& s, int wave, in
     s.tab_n[wave] = n <= s.tab_units ? n : 0;
     s.tab_n[NWAVES + wave] = n <= s.tab_units ? lead : P;
   }
+}
+
+// The schedule table behind the packed weights.  Building it takes a wave ~25 k cycles of scalar
+// code (ten microseconds per launch of every kernel that runs the networks), and it depends on
+// the layer shapes only, so az_model_pack builds it once, with these same functions
+// (k_table_build), and leaves it behind the weights:
+//   word 0 az_mlp_table_hash of the model it was built for, word 1 its rows per wave (tab_units),
+//   words 2-3 the address `packed` had at that time, words 4-19 MlpLds::tab_n, then
+//   MlpLds::tab ([AZ_MLP_WAVES][tab_units][AZ_UNIT_WORDS]).
+// A kernel whose model matches the header copies it into LDS (az_mlp_table_load), moving the
+// pointers inside by the distance the buffer has moved since; any other buffer -- packed for other
+// shapes, or not by az_model_pack -- makes the kernel build the table itself as before.
+#define AZ_TABLE_HDR_WORDS 20
+#define AZ_TABLE_MAX_WORDS (AZ_TABLE_HDR_WORDS + AZ_MLP_WAVES * AZ_TABLE_UNITS * AZ_UNIT_WORDS)
+static_assert(AZ_TABLE_MAX_WORDS % 4 == 0 && AZ_UNIT_WORDS % 2 == 0, "the table is copied in 8-byte pairs");
+static_assert(offsetof(MlpUnit, w0) == 0 && offsetof(MlpUnit, w1) == 8 && offsetof(MlpUnit, w2) == 16 &&
+                  offsetof(MlpUnit, o0) + offsetof(MlpTile, bias) == 24 &&
+                  offsetof(MlpUnit, o2) + offsetof(MlpTile, bias) == 56,
+              "pairs 0, 1, 2, 3 and 7 of a unit are its pointers (az_mlp_table_load)");
+
+__host__ __device__ inline uint32_t az_mlp_table_hash(const ModelDev& md) {
+  uint32_t h = 2166136261u;
+  auto mix = [&](int v) { h = (h ^ (uint32_t)v) * 16777619u; };
+  for (int net = 0; net < 2; ++net) {
+    const MlpLayout& L = net ? md.val : md.pol;
+    mix(L.n_layers);
+    for (int i = 0; i < L.n_layers; ++i) {
+      mix(L.kin[i]);
+      mix(L.nout[i]);
+      mix(L.wb[i]);
+      mix((int)L.w_off[i]);
+      mix((int)L.b_off[i]);
+    }
+  }
+  mix(md.bf16);
+  mix(md.tab_units);
+  mix(md.head_floats);
+  mix(AZ_UNIT_WORDS * 1000 + AZ_TABLE_UNITS);
+  return h | 1u;  // never 0: a zeroed header matches nothing
+}
+
+// Workgroup-wide; true when the table was taken from the packed buffer (the caller's barrier
+// publishes it, as it does a table built in place).
+AZ_DEV bool az_mlp_table_load(const ModelDev& md, const MlpLds& s, int tid, int nthreads) {
+  const uint32_t* g = md.table;
+  if (g == nullptr) return false;
+  const uint32_t h0 = __builtin_amdgcn_readfirstlane(g[0]), h1 = __builtin_amdgcn_readfirstlane(g[1]);
+  if (h0 != md.table_hash || (int)h1 != md.tab_units) return false;
+  const uint64_t* g2 = reinterpret_cast<const uint64_t*>(g);
+  const uint64_t delta = (uint64_t)(uintptr_t)md.packed - g2[1];
+  for (int i = tid; i < 16; i += nthreads) s.tab_n[i] = (int32_t)g[4 + i];
+  const int pairs = AZ_MLP_WAVES * md.tab_units * (AZ_UNIT_WORDS / 2);
+  uint64_t* dst = reinterpret_cast<uint64_t*>(s.tab);
+  for (int p = tid; p < pairs; p += nthreads) {
+    const int q = p % (AZ_UNIT_WORDS / 2);
+    uint64_t v = g2[AZ_TABLE_HDR_WORDS / 2 + p];
+    if (q < 4 || q == 7) v += delta;
+    dst[p] = v;
+  }
+  return true;
+}
+
+template <int NWAVES>
+AZ_DEV void az_mlp_table_setup(const ModelDev& md, const MlpLds& s, int tid, int nthreads, int wave, int lane) {
+  if (!az_mlp_table_load(md, s, tid, nthreads)) az_mlp_table_build<NWAVES>(md, s, wave, lane);
 }
 
 // One LDS access for everything a wave needs at the start of unit `i`: lane k < AZ_UNIT_WORDS

@@ -178,9 +178,14 @@ int az_expand_backward(const az_search_desc* d, const az_tree* t, const int32_t*
                        const float* value, const float* reward, const float* discount,
                        void* stream);
 
-/* Size in floats of the packed-weight buffer of a model with these networks. */
+/* Size in floats of the packed-weight buffer of a model with these networks: the re-laid-out
+ * weights and biases followed by a fixed-size block for the networks' work schedule. */
 int64_t az_model_packed_floats(const az_mlp_params* policy, const az_mlp_params* value);
-/* Re-lays the flax-layout weights out for the matrix cores into `packed`. */
+/* Re-lays the flax-layout weights out for the matrix cores into `packed` and leaves the networks'
+ * work schedule (which wave multiplies which tiles in which order: a function of the layer shapes
+ * only) behind them, so that the kernels copy it instead of working it out at every launch.  The
+ * buffer may be copied or moved afterwards (the schedule's addresses are adjusted by the distance);
+ * a kernel that finds no schedule for its model's shapes there builds its own. */
 int az_model_pack(const az_mlp_params* policy, const az_mlp_params* value, float* packed,
                   void* stream);
 

@@ -230,6 +230,48 @@ def test_forward_network_shapes_vs_oracle(hip, oracle, policy_hidden, value_hidd
     assert np.array_equal(lg.cpu().numpy(), rl) and np.array_equal(val.cpu().numpy(), rv)
 
 
+@pytest.mark.parametrize("policy_hidden,value_hidden,K", [((32, 32, 32), (256, 256, 256, 256, 256), 1),
+                                                          ((48, 600, 128, 64), (100, 200), 1),
+                                                          ((64,), (64,), 1)])
+def test_schedule_table_sources_agree(hip, oracle, policy_hidden, value_hidden, K):
+    """The networks' schedule table comes from behind the packed weights (az_model_pack builds it):
+    as packed, from a copy of the buffer at another address (the pointers inside are moved by the
+    distance), and -- header wiped, as for a buffer that az_model_pack did not fill -- built by the
+    kernel itself.  All three give the checker's bits, through the forward kernel and one model step."""
+    import alphazero_amd as mctx
+    rng = np.random.default_rng(4)
+    env_id = "CartPole-v1"
+    case = runners.synthetic_case("gumbel", B=21, S=1, K=K, seed=4, env_id=env_id, random_bias=True,
+                                  policy_hidden=policy_hidden, value_hidden=value_hidden)
+    model = case["model"]
+    fm = hip.make_model(model)
+    md = oracle.make_model(env_id, model["policy_layers"], model["value_layers"], model["mean"], model["std"])
+    obs = rng.uniform(-2, 2, (21, 4)).astype(np.float32)
+    rl, rv = oracle.forward(md, obs)
+    weights = fm.packed.numel() - (20 + 8 * 16 * 36)  # az_mlp.h: header + [8 waves][16 units][36 words]
+    header = fm.packed[weights:weights + 2].view(torch.int32).cpu().numpy()
+    assert header[0] != 0 and 1 <= header[1] <= 16
+    st = mctx.envs.make(env_id).reset(0, batch_size=21)
+    act = hip.dev(rng.integers(0, 2, 21).astype(np.int32))
+    rf = mctx.FusedRecurrentFn(fm)
+    ref_step = None
+    for mode in ("packed", "moved", "wiped"):
+        if mode == "moved":
+            pad = torch.empty(4099, dtype=torch.float32, device=fm.packed.device)  # (keeps the copy off the old address)
+            fm.packed = fm.packed.clone()
+            del pad
+        elif mode == "wiped":
+            fm.packed[weights:weights + 20] = 0
+        fm.native.packed = fm.packed.data_ptr()
+        lg, val = fm.forward(hip.dev(obs))
+        assert np.array_equal(lg.cpu().numpy(), rl) and np.array_equal(val.cpu().numpy(), rv), mode
+        out, emb = rf((), None, act, st.embedding)
+        step = [x.cpu().numpy() for x in (out.prior_logits, out.value, out.reward, emb["state"])]
+        if ref_step is None:
+            ref_step = step
+        assert all(np.array_equal(a, b) for a, b in zip(step, ref_step)), mode
+
+
 FUSED_CASES = [
     ("CartPole-v1", "gumbel", 40, 16, 1, {}),
     ("CartPole-v1", "gumbel", 20, 256, 1, {}),   # the S of the largest baseline configuration

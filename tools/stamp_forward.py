@@ -19,6 +19,12 @@ buf = np.zeros((8, 64), np.int64)
 lib.az_debug_read_stamps.argtypes = [C.c_void_p]
 lib.az_debug_read_stamps(buf.ctypes.data_as(C.c_void_p))
 t0 = buf[:, 0].min()
+edges = buf[:, 60:64].copy()
+buf[:, 60:64] = 0
+if edges.any():  # kernel entry -> inputs staged -> table built -> weights requested -> first stamp of the forward
+    for w in range(8):
+        e = edges[w]
+        print(f"wave {w} entry: stage {int(e[1] - e[0])}  table+barrier {int(e[2] - e[1])}  obs+prime {int(e[3] - e[2])}  -> forward {int(buf[w, 0] - e[3])}  (entry to forward {int(buf[w, 0] - e[0])})")
 for w in range(8):
     row = buf[w]
     n = int((row > 0).sum())
