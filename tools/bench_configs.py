@@ -19,7 +19,7 @@ for variant, env_id, B, S in CASES:
     logits, value = model.forward(st.obs)
     root = mctx.RootFnOutput(prior_logits=logits, value=value, embedding=st.embedding)
     ts = []
-    for i in range(4):
+    for i in range(6):  # two warm-up searches (cold caches, first-launch set-up), then the minimum of four
         stats = {"record_events": True}
         if variant == "gumbel":
             mctx.gumbel_muzero_policy((), i, root, rf, S, stats=stats)
@@ -28,6 +28,7 @@ for variant, env_id, B, S in CASES:
         else:
             mctx.sampled_muzero_policy((), i, root, rf, S, num_samples=16, stats=stats)
         torch.cuda.synchronize()
-        ts.append(stats["events"][0][0].elapsed_time(stats["events"][0][1]))
+        if i >= 2:
+            ts.append(stats["events"][0][0].elapsed_time(stats["events"][0][1]))
     print(f"{variant:8s} {env_id:15s} B={B:6d} S={S:4d}: {min(ts):8.3f} ms  {B*S/min(ts)/1e3:7.1f} M sims/s  "
           f"mean depth {stats['sum_depth'].item()/(B*S):.1f}", flush=True)
