@@ -138,6 +138,7 @@ SIGNATURES = {
     "az_actor_post": (C.c_int, [C.POINTER(SearchDesc), C.POINTER(TreePtrs), _P, _P, _I, _P, _P,
                                 _P, _P, _P]),
     "az_split_keys": (C.c_int, [_P, _I, _P, _P]),
+    "az_random_sort_keys": (C.c_int, [_P, _I, _P, _P]),
     "az_breakout_reset": (C.c_int, [_I, _P, _P, _P, _P, _P]),
     "az_breakout_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "az_breakout_real_step": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

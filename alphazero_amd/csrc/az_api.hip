@@ -476,6 +476,18 @@ extern "C" int az_split_keys(const uint32_t* key_host, int32_t n, uint32_t* out,
   return AZ_OK;
 }
 
+__global__ void k_random_sort_keys(uint32_t k0, uint32_t k1, int n, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int64_t)az_random_bits32(k0, k1, (uint32_t)i);
+}
+
+extern "C" int az_random_sort_keys(const uint32_t* key_host, int32_t n, int64_t* out, void* stream) {
+  if (!key_host || n < 1 || !out) return az_fail(AZ_ERR_INVALID, "bad random_sort_keys arguments");
+  k_random_sort_keys<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(key_host[0], key_host[1], n, out);
+  AZ_LAUNCH_CHECK();
+  return AZ_OK;
+}
+
 __global__ void k_env_reset(int env_id, int B, const uint32_t* __restrict__ keys,
                             float* __restrict__ state, int32_t* __restrict__ time,
                             float* __restrict__ obs, uint32_t* __restrict__ rng_out) {

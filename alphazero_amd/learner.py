@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import prng
+
 
 # ---------------------------------------------------------------- targets
 def n_step_bootstrapped_targets(rewards, discounts, termination_discount, observations, values,
@@ -345,17 +347,43 @@ class GraphedMinibatchStep:
         return {k: out[i] for i, k in enumerate(self.METRICS)}
 
 
+def permutation(key, n, device):
+    """prng.permutation(key, n) as a tensor on `device`.  On a GPU the rounds' sort keys come from
+    az_random_sort_keys and the stable sorts run there too: nothing crosses the host."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return torch.from_numpy(prng.permutation(key, n)).to(device)
+    import ctypes as C
+    import math
+    from . import _native as nat
+    x = torch.arange(n, device=device)
+    bits = torch.empty((n,), dtype=torch.int64, device=device)
+    key = prng.as_key(key)
+    for _ in range(int(math.ceil(3 * math.log(max(1, n)) / math.log(2 ** 32 - 1)))):
+        key, subkey = prng.split(key, 2)
+        nat.check(nat.lib().az_random_sort_keys((C.c_uint32 * 2)(*subkey), n, nat.ptr(bits), nat.stream_ptr()))
+        x = x[torch.sort(bits, stable=True).indices]
+    return x
+
+
 def sgd_step(policy_layers, value_layers, mean, std, data, optimizer, num_atoms, num_minibatches,
-             generator=None, rows=None, layout=None, graphed=None, **loss_kw):
+             generator=None, rows=None, layout=None, graphed=None, key=None, **loss_kw):
     """alphazero.py:1074-1089: one permutation of the sampled batch, split into
     `num_minibatches`, one optimiser update per minibatch.
+    key (optional): this step's carry key; the permutation is then jax.random.permutation's under
+    key_perm (prng.permutation), otherwise it comes from torch.randperm(generator).
     rows / layout (optional): the packed rows `data` was unpacked from (unpack_rows); they are
     permuted once and the minibatches' fields are views of the result, instead of one gather
     per field and minibatch.  graphed (optional, needs rows): a GraphedMinibatchStep that runs the
     minibatches in place of minibatch_step."""
     n = next(iter(data.values())).shape[0]
     dev = next(iter(data.values())).device
-    perm = torch.randperm(n, generator=generator, device=dev)
+    if key is not None:
+        # key, key_perm, key_grad = split(key, 3) (:1076); key_grad reaches a loss that draws nothing
+        _, key_perm, _ = prng.split(key, 3)
+        perm = permutation(key_perm, n, dev)
+    else:
+        perm = torch.randperm(n, generator=generator, device=dev)
     metrics = []
     if rows is not None:
         shuffled = rows[perm].reshape(num_minibatches, -1, rows.shape[1])

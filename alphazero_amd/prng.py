@@ -52,3 +52,36 @@ def split(rng_key, num=2):
 
 def key_array(key):
     return (np.uint32(key[0]), np.uint32(key[1]))
+
+
+def random_bits32(key, n):
+    """n words of jax.random.bits(key, (n,), uint32) in the partitionable layout: word i is
+    the xor of the two outputs of the threefry-2x32 block with counter (0, i).  NumPy, vectorised
+    over i (the device counterpart is az_random_bits32 in csrc/az_math.h)."""
+    k0, k1 = (np.uint32(w) for w in as_key(key))
+    ks = (k0, k1, np.uint32(k0 ^ k1 ^ np.uint32(0x1BD11BDA)))
+    with np.errstate(over="ignore"):
+        x0 = np.zeros(n, np.uint32) + ks[0]
+        x1 = np.arange(n, dtype=np.uint32) + ks[1]
+        for block in range(5):
+            for r in _ROT[block % 2]:
+                x0 = x0 + x1
+                x1 = ((x1 << np.uint32(r)) | (x1 >> np.uint32(32 - r))) ^ x0
+            x0 = x0 + ks[(block + 1) % 3]
+            x1 = x1 + ks[(block + 2) % 3] + np.uint32(block + 1)
+    return x0 ^ x1
+
+
+def permutation(key, n):
+    """jax.random.permutation(key, n) -- and, the keys depending on n alone, the order in which
+    jax.random.permutation(key, x) leaves the rows of any x with n rows -- as jax._src.random._shuffle
+    does it: ceil(3 ln n / ln(2^32 - 1)) rounds of `key, subkey = split(key)`, 32 random bits per
+    element from subkey, stable sort by those bits.  Returns int64 indices (NumPy)."""
+    n = int(n)
+    x = np.arange(n, dtype=np.int64)
+    rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+    key = as_key(key)
+    for _ in range(rounds):
+        key, subkey = split(key, 2)
+        x = x[np.argsort(random_bits32(subkey, n), kind="stable")]
+    return x

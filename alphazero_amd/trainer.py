@@ -233,14 +233,15 @@ class Trainer:
     def training_step(self):
         """alphazero.py:1092-1183."""
         cfg = self.cfg
-        # key_sgd, key_generate_unroll, key_bootstrap, reanalyze_key, new_key (:1097); the
-        # minibatch permutation draws from a torch generator instead of key_sgd
-        _, k_unroll, k_boot, _, self.key = prng.split(self.key, 5)
+        # key_sgd, key_generate_unroll, key_bootstrap, reanalyze_key, new_key (:1097)
+        k_sgd, k_unroll, k_boot, _, self.key = prng.split(self.key, 5)
         flat = self.collect(k_unroll, k_boot)
-        return self.learn(flat)
+        return self.learn(flat, k_sgd)
 
-    def learn(self, flat):
-        """alphazero.py:1153-1183: statistics, sample, SGD, priority refresh."""
+    def learn(self, flat, key_sgd=None):
+        """alphazero.py:1153-1183: statistics, sample, SGD, priority refresh.  key_sgd: the carry
+        key of the SGD steps (:1167), which orders the minibatches (jax.random.permutation under
+        each step's key_perm, :1076-1079); without it the order comes from a torch generator."""
         cfg = self.cfg
         if cfg.normalize_observations:
             self.stats.update(flat["observation"])
@@ -260,10 +261,12 @@ class Trainer:
             metrics += L.sgd_step(self.policy_layers, self.value_layers, mean, std, batch,
                                   self.optimizer, cfg.num_atoms, cfg.num_minibatches,
                                   generator=self._perm_gen, rows=rows, layout=self.layout,
-                                  graphed=self._graphed,
+                                  graphed=self._graphed, key=key_sgd,
                                   qr_kappa=cfg.qr_kappa, vf_cost=cfg.vf_cost,
                                   l2_coef=cfg.l2_coef,
                                   per_importance_sampling=cfg.per_importance_sampling)
+            if key_sgd is not None:
+                key_sgd = prng.split(key_sgd, 3)[0]   # the carry of sgd_step (:1076, :1089)
         # refresh the priorities of the sampled rows with the PRE-update networks (:1177-1180)
         targets = batch["value_prefix_target"].unsqueeze(-1) + \
             batch["bootstrap_discount"].unsqueeze(-1) * batch["bootstrap_value"]

@@ -268,6 +268,10 @@ int az_actor_post(const az_search_desc* d, const az_tree* t, const float* action
 /* jax.random.split(key, n) in the partitionable counter layout: out [n,2] (used as
  * alphazero.py does to derive one reset key per environment). */
 int az_split_keys(const uint32_t* key_host, int32_t n, uint32_t* out, void* stream);
+/* jax.random.bits(key, (n,), uint32) in the partitionable counter layout, zero-extended to
+ * int64 out[n]: the sort keys of one round of jax.random.permutation (alphazero.py:1079 shuffles
+ * the sampled batch with it; the rounds' key splits and stable sorts are the caller's). */
+int az_random_sort_keys(const uint32_t* key_host, int32_t n, int64_t* out, void* stream);
 /* reset of the wrapped environment (gymnax/wrappers/brax.py:41-55 on top of the
  * reset_env of the classic_control envs): keys [B,2] -> state [B,4], time [B],
  * obs [B,obs_dim], and rng_out [B,2] = split(key)[0], the key the wrapper stores in

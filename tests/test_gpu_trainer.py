@@ -310,3 +310,13 @@ def test_graph_replayed_minibatch_updates_equal_the_eager_ones(atoms, per_alpha)
     for a, b in zip(eager.optimizer.params + eager.optimizer.m + eager.optimizer.v,
                     graphed.optimizer.params + graphed.optimizer.m + graphed.optimizer.v):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-8)
+
+
+def test_minibatch_permutation_on_the_device_equals_the_host_one():
+    """learner.permutation on the GPU (az_random_sort_keys + stable sorts) = prng.permutation (NumPy),
+    for one and two rounds of sorting."""
+    import numpy as np
+    from alphazero_amd import learner as L, prng
+    for key, n in (((0, 3), 1), ((7, 8), 37), ((0, 9), 1625), ((1, 2), 4096), ((5, 5), 16384)):
+        got = L.permutation(key, n, "cuda").cpu().numpy()
+        assert np.array_equal(got, prng.permutation(key, n)), (key, n)

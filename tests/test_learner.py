@@ -256,3 +256,36 @@ def test_float32_gpu_vs_float64_oracle():
         close(out, ref, 1e-5)
         for k in rm:
             close(m[k], rm[k], 1e-5)
+
+
+def test_key_driven_minibatch_permutation():
+    """prng.permutation restates jax.random.permutation (jax._src.random._shuffle: rounds of split,
+    32 random bits per element, stable sort) on the partitionable threefry stream.  Checked here
+    against a scalar restatement on Python ints, for the number of rounds, and that sgd_step orders
+    its minibatches by it (key, key_perm, key_grad = split(key, 3), alphazero.py:1076-1079).
+    Parity unpinned: no JAX here and no recorded permutation in the reference."""
+    import math
+    from alphazero_amd import prng
+    for key, n in (((0, 7), 1), ((3, 9), 5), ((0, 42), 1625), ((11, 12), 1626), ((0, 1), 4099)):
+        rounds = math.ceil(3 * math.log(max(1, n)) / math.log(2 ** 32 - 1))
+        assert rounds == (0 if n == 1 else 1 if n <= 1625 else 2)
+        k, x = key, list(range(n))
+        for _ in range(rounds):
+            k, sub = prng.split(k, 2)
+            bits = [a ^ b for a, b in (prng.threefry2x32(sub, (0, i)) for i in range(n))]
+            x = [x[i] for i in sorted(range(n), key=lambda i: bits[i])]   # (sorted is stable)
+        got = prng.permutation(key, n)
+        assert got.tolist() == x and sorted(x) == list(range(n))
+    # sgd_step: minibatch i holds rows perm[i * m : (i + 1) * m]
+    torch.manual_seed(0)
+    n, nmb = 24, 4
+    data = {"observation": torch.arange(n, dtype=torch.float64).reshape(n, 1)}
+    seen = []
+    orig = L.minibatch_step
+    L.minibatch_step = lambda pl, vl, mean, std, mb, *a, **kw: seen.append(mb["observation"].flatten().tolist()) or {}
+    try:
+        L.sgd_step(None, None, None, None, data, None, 1, nmb, key=(5, 6))
+    finally:
+        L.minibatch_step = orig
+    perm = prng.permutation(prng.split((5, 6), 3)[1], n)
+    assert [int(v) for mb in seen for v in mb] == perm.tolist()
