@@ -111,11 +111,11 @@ class Actor:
         return out
 
 
-def secondary_sampled(args, B, S, device, steps=5):
+def secondary_sampled(args, B, S, device, steps=10):
     """The same actor step with the reference trainer's default policy, sampled_muzero_policy with
     100 samples (PUCT with Dirichlet noise at the root and tie-break noise in the tree)."""
     actor = Actor(args.env, B, S, device, seed=7, variant="sampled")
-    for _ in range(2):
+    for _ in range(3):
         actor.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
