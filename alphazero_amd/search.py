@@ -136,12 +136,10 @@ def build_desc(*, B, S, A, K, root_action_selection_fn, interior_action_selectio
 
 
 # Every search needs a device int64 that starts at zero (the kernels add the depths of the expanded
-# nodes to it), and a search without invalid actions an all-zero [B, A] mask for its Tree.  A fill
-# kernel for each is ~3.5 us of the GPU's time per search -- as much as the root's selection kernel --
-# so the zeros come out of a pool filled 4096 at a time, one fresh slot per search, and the
-# all-zero mask (never written by this package) is shared between the Trees of one shape.
+# nodes to it).  A fill kernel for it is ~3.5 us of the GPU's time per search -- as much as the
+# root's selection kernel -- so the zeros come out of a pool filled 4096 at a time, one fresh slot
+# per search (a slot is never handed out twice).
 _zero_pools = {}
-_no_invalid_masks = {}
 
 
 def _zero_slot(dev):
@@ -151,16 +149,6 @@ def _zero_slot(dev):
     slot = pool[0][pool[1]:pool[1] + 1]
     pool[1] += 1
     return slot
-
-
-def _no_invalid(B, A, dev):
-    key = (B, A, dev)
-    mask = _no_invalid_masks.get(key)
-    if mask is None:
-        if len(_no_invalid_masks) > 64:
-            _no_invalid_masks.clear()
-        mask = _no_invalid_masks[key] = torch.zeros((B, A), dtype=torch.float32, device=dev)
-    return mask
 
 
 def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
@@ -323,6 +311,6 @@ def search(params, rng_key, *, root, recurrent_fn, root_action_selection_fn,
 
     if stats is not None:
         stats["sum_depth"] = sum_depth
-    root_invalid = inv if inv is not None else _no_invalid(B, A, dev)
+    root_invalid = inv if inv is not None else torch.zeros_like(logits)
     return Tree(embeddings=embeddings, root_invalid_actions=root_invalid, extra_data=extra_data,
                 **arrays)
